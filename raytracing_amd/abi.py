@@ -1,0 +1,160 @@
+"""ctypes binding of the C ABI (include/rtmi.h) for callers that own device memory and streams.
+
+Used by bench.py, the multi-GPU path and the GPU parity tests.  Nothing here computes: it only
+marshals pointers into ``librtmi.so``.
+"""
+import ctypes as C
+import os
+
+from . import LIB_PATH
+
+N_STATS = 8
+STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_tests", "node_visits", "overflow")
+
+# every symbol include/rtmi.h declares
+SYMBOLS = (
+    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device",
+    "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
+)
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("max_samples", C.c_int32), ("precision", C.c_int32), ("rank", C.c_int32),
+                ("nranks", C.c_int32), ("tile_rows", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("counter", C.c_uint64 * N_STATS), ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        d = {k: int(self.counter[i]) for i, k in enumerate(STAT_NAMES)}
+        d["kernel_ms"] = float(self.kernel_ms)
+        return d
+
+
+class HitRecord(C.Structure):
+    _fields_ = [("hit", C.c_int32), ("leaf", C.c_int32), ("inside", C.c_int32), ("reserved", C.c_int32), ("t", C.c_double),
+                ("point", C.c_double * 3), ("normal", C.c_double * 3), ("n1", C.c_double), ("n2", C.c_double),
+                ("shadowed", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("librtmi.so missing at %s: run `make -C raytracing_amd/csrc`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rtmi_last_error.restype = C.c_char_p
+        L.rtmi_rank_rows.restype = C.c_int32
+        L.rtmi_rank_rows.argtypes = [C.c_int32] * 4
+        L.rtmi_scene_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rtmi_scene_destroy.argtypes = [C.c_void_p]
+        L.rtmi_scene_destroy.restype = None
+        L.rtmi_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.POINTER(Stats)]
+        L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtmi_tonemap_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rtmi_trace_rays.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
+        L.rtmi_camera_rays.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        L.rtmi_describe.argtypes = [C.c_char_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+class RtmiError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RtmiError("%s failed (%d): %s" % (what, rc, lib().rtmi_last_error().decode()))
+
+
+def describe():
+    buf = C.create_string_buffer(512)
+    check(lib().rtmi_describe(buf, 512), "rtmi_describe")
+    return buf.value.decode()
+
+
+def rank_rows(vsize, rank, nranks, tile_rows=8):
+    return int(lib().rtmi_rank_rows(vsize, rank, nranks, tile_rows))
+
+
+def make_opts(seed=0x5EED, max_samples=0, precision=0, rank=0, nranks=1, tile_rows=8):
+    return RenderOpts(seed, max_samples, precision, rank, nranks, tile_rows, 0)
+
+
+class Scene:
+    """Device-resident scene created from a flattened World (rtmi_scene_create)."""
+
+    def __init__(self, world):
+        self._flat = world.flatten()
+        h = C.c_void_p()
+        check(lib().rtmi_scene_create(self._flat.desc_address(), C.byref(h)), "rtmi_scene_create")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().rtmi_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_host(scene, camera, opts=None):
+    """Camera::render through rtmi_render: returns (float32 image [v,h,3], stats dict)."""
+    import numpy as np
+    opts = opts or make_opts()
+    cam = camera.abi()
+    out = np.empty((camera.vsize(), camera.hsize(), 3), dtype=np.float32)
+    st = Stats()
+    check(lib().rtmi_render(scene.handle, cam.address(), C.byref(opts), out.ctypes.data, C.byref(st)), "rtmi_render")
+    return out, st.as_dict()
+
+
+def render_device(scene, camera, opts, out_tensor, stats_tensor=None, stream=0):
+    """rtmi_render_device on torch tensors (out: float32 [rows,h,3] on the GPU; stats: int64 [8] or None)."""
+    cam = camera.abi()
+    sp = stats_tensor.data_ptr() if stats_tensor is not None else None
+    check(lib().rtmi_render_device(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream), "rtmi_render_device")
+
+
+def tonemap_u8_device(rgb_tensor, out_tensor, stream=0):
+    check(lib().rtmi_tonemap_u8_device(rgb_tensor.data_ptr(), out_tensor.data_ptr(), rgb_tensor.numel(), stream), "rtmi_tonemap_u8_device")
+
+
+def trace_rays(scene, origins, directions, remaining=None, opts=None, want_hits=True):
+    """World::color_at for a batch of rays: returns (rgb float64 [n,3], list of HitRecord or None)."""
+    import numpy as np
+    opts = opts or make_opts()
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    n = o.shape[0]
+    rem = None if remaining is None else np.ascontiguousarray(remaining, dtype=np.int32)
+    rgb = np.zeros((n, 3), dtype=np.float64)
+    recs = (HitRecord * n)() if want_hits else None
+    check(lib().rtmi_trace_rays(scene.handle, C.byref(opts), n, o.ctypes.data, d.ctypes.data, rem.ctypes.data if rem is not None else None,
+                                rgb.ctypes.data, C.cast(recs, C.c_void_p) if recs is not None else None), "rtmi_trace_rays")
+    return rgb, recs
+
+
+def camera_rays(camera, px, py, sample=None, opts=None):
+    import numpy as np
+    opts = opts or make_opts()
+    cam = camera.abi()
+    px = np.ascontiguousarray(px, dtype=np.int32)
+    py = np.ascontiguousarray(py, dtype=np.int32)
+    n = px.shape[0]
+    s = None if sample is None else np.ascontiguousarray(sample, dtype=np.int32)
+    o = np.zeros((n, 3)); d = np.zeros((n, 3))
+    check(lib().rtmi_camera_rays(cam.address(), C.byref(opts), n, px.ctypes.data, py.ctypes.data, s.ctypes.data if s is not None else None,
+                                 o.ctypes.data, d.ctypes.data), "rtmi_camera_rays")
+    return o, d

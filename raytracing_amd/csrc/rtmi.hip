@@ -1,0 +1,699 @@
+// rtmi.hip — C ABI (include/rtmi.h) of the MI355X ray-casting core: scene layout + upload, kernels, launches.
+// gfx950 only.  No CPU fallback: without a usable HIP device every compute entry point fails with
+// RTMI_ERR_DEVICE and a message.
+#include "rtmi_device.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtmi_dev;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+extern "C" const char *rtmi_last_error(void) { return g_err.c_str(); }
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *stats) {
+    if (!stats) return;
+#pragma unroll
+    for (int i = 0; i < RTMI_N_STATS; ++i) {
+        uint32_t s = wave_sum(st.c[i]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
+    }
+}
+
+// Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310): one wave64 per 8x8 pixel tile,
+// waves stride over the tiles this rank owns.
+template <typename R>
+__global__ void __launch_bounds__(64) render_kernel(DScene<R> sc, DCamera<R> cam, DRender rp, float *__restrict__ out,
+                                                    unsigned long long *stats) {
+    Stats st;
+#pragma unroll
+    for (int i = 0; i < RTMI_N_STATS; ++i) st.c[i] = 0;
+    Rng rng;
+    rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
+    const int lane = threadIdx.x & 63;
+    const int sub = rp.tile_rows >> 3; // 8-row rows per ownership tile
+    for (int tile = blockIdx.x; tile < rp.n_tiles; tile += gridDim.x) {
+        int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
+        int lt = ltr / sub, within = ltr - lt * sub;
+        int gt = lt * rp.nranks + rp.rank;
+        int x = tx * 8 + (lane & 7);
+        int y = (gt * sub + within) * 8 + (lane >> 3);
+        int ly = ltr * 8 + (lane >> 3);
+        if (x >= cam.hsize || y >= cam.vsize) continue;
+        uint32_t pixel = (uint32_t)(y * cam.hsize + x);
+        V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
+        R n = 0;
+        for (uint32_t s = 0;; ++s) {
+            if (s > 0) { // camera.rs:281,290-291
+                bool more = n < (R)cam.min_samples;
+                if (!more) { // color_variance_of_mean, camera.rs:305-310
+                    R inv_n = (R)1 / n;
+                    V3<R> mean = sum * inv_n;
+                    V3<R> var = sos * inv_n - had(mean, mean);
+                    R variance = (var.x + var.y + var.z) / (R)3;
+                    more = variance / n > cam.se2;
+                }
+                if (!more) break;
+                if (cam.max_samples > 0 && s >= (uint32_t)cam.max_samples) break;
+            }
+            rng_begin(rng, pixel, s);
+            st.c[RTMI_STAT_SAMPLES]++;
+            Ray<R> ray = ray_for_pixel(cam, x, y, s != 0, rng);
+            V3<R> c = color_at<R>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
+            sum = sum + c;
+            sos = sos + had(c, c);
+            n += (R)1;
+        }
+        R inv_n = (R)1 / n;
+        size_t o = ((size_t)ly * cam.hsize + x) * 3;
+        out[o + 0] = (float)(sum.x * inv_n);
+        out[o + 1] = (float)(sum.y * inv_n);
+        out[o + 2] = (float)(sum.z * inv_n);
+    }
+    flush_stats(st, stats);
+}
+
+// World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays)
+template <typename R>
+__global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
+                                                   const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Stats st;
+#pragma unroll
+    for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
+    Rng rng;
+    rng.k0 = seed_lo; rng.k1 = seed_hi;
+    rng_begin(rng, (uint32_t)i, 0);
+    Ray<R> ray = {mk<R>((R)origins[3 * i], (R)origins[3 * i + 1], (R)origins[3 * i + 2]),
+                  mk<R>((R)dirs[3 * i], (R)dirs[3 * i + 1], (R)dirs[3 * i + 2])};
+    Hit<R> h;
+    Comps<R> c;
+    c.point = mk<R>(0, 0, 0); c.normalv = c.point; c.eyev = c.point; c.inside = false; c.n1 = 1; c.n2 = 1;
+    int rem = remaining ? remaining[i] : (int)sc.max_depth;
+    V3<R> col = color_at<R>(sc, ray, rem, rng, st, &h, &c);
+    if (rgb) { rgb[3 * i] = (double)col.x; rgb[3 * i + 1] = (double)col.y; rgb[3 * i + 2] = (double)col.z; }
+    if (recs) {
+        rtmi_hit_record r;
+        memset(&r, 0, sizeof r);
+        r.shadowed = -1.0;
+        if (h.leaf != NONE) {
+            r.hit = 1;
+            r.leaf = (int32_t)sc.leaf_orig[h.leaf];
+            r.inside = c.inside ? 1 : 0;
+            r.t = (double)h.t;
+            r.point[0] = (double)c.point.x; r.point[1] = (double)c.point.y; r.point[2] = (double)c.point.z;
+            r.normal[0] = (double)c.normalv.x; r.normal[1] = (double)c.normalv.y; r.normal[2] = (double)c.normalv.z;
+            r.n1 = (double)c.n1; r.n2 = (double)c.n2;
+            if (sc.n_lights > 0) {
+                int k = sc.lights[0].kind;
+                if (k == RTMI_LIGHT_POINT || k == RTMI_LIGHT_REALISTIC_POINT || k == RTMI_LIGHT_BEAM) {
+                    V3<R> over_point = c.point + c.normalv * (R)RTMI_EPSILON;
+                    Incoming<R> in = incoming_at(sc.lights[0], over_point, rng);
+                    if (in.kind == IL_RAY) r.shadowed = is_shadowed(sc, in, over_point, h.leaf, st) ? 1.0 : 0.0;
+                }
+            }
+        }
+        recs[i] = r;
+    }
+}
+
+// Camera::ray_for_pixel for a batch of (px, py, sample) (rtmi_camera_rays)
+template <typename R>
+__global__ void camera_rays_kernel(DCamera<R> cam, uint32_t seed_lo, uint32_t seed_hi, long long n, const int *px, const int *py,
+                                   const int *sample, double *origins, double *dirs) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rng;
+    rng.k0 = seed_lo; rng.k1 = seed_hi;
+    int s = sample ? sample[i] : 0;
+    rng_begin(rng, (uint32_t)(py[i] * cam.hsize + px[i]), (uint32_t)s);
+    Ray<R> r = ray_for_pixel(cam, px[i], py[i], s != 0, rng);
+    origins[3 * i] = (double)r.o.x; origins[3 * i + 1] = (double)r.o.y; origins[3 * i + 2] = (double)r.o.z;
+    dirs[3 * i] = (double)r.d.x; dirs[3 * i + 1] = (double)r.d.y; dirs[3 * i + 2] = (double)r.d.z;
+}
+
+// Color::to_u8 (color.rs:53-60): clip, x255, round half away from zero.  4 values per lane.
+__global__ void tonemap_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n && (((uintptr_t)(in + i)) & 15) == 0 && (((uintptr_t)(out + i)) & 3) == 0) {
+        float4 v = *reinterpret_cast<const float4 *>(in + i);
+        uint32_t a = (uint32_t)floorf(fminf(fmaxf(v.x, 0.f), 1.f) * 255.f + 0.5f);
+        uint32_t b = (uint32_t)floorf(fminf(fmaxf(v.y, 0.f), 1.f) * 255.f + 0.5f);
+        uint32_t c = (uint32_t)floorf(fminf(fmaxf(v.z, 0.f), 1.f) * 255.f + 0.5f);
+        uint32_t d = (uint32_t)floorf(fminf(fmaxf(v.w, 0.f), 1.f) * 255.f + 0.5f);
+        *reinterpret_cast<uint32_t *>(out + i) = a | (b << 8) | (c << 16) | (d << 24);
+    } else {
+        for (long long k = i; k < n && k < i + 4; ++k) out[k] = (uint8_t)floorf(fminf(fmaxf(in[k], 0.f), 1.f) * 255.f + 0.5f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: scene layout
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct DeviceArrays {
+    DLeaf<R> *leaves = nullptr;
+    DTri<R> *tris = nullptr;
+    DMaterial<R> *materials = nullptr;
+    DPattern<R> *patterns = nullptr;
+    DLight<R> *lights = nullptr;
+};
+
+struct rtmi_scene {
+    int device = -1;
+    DeviceArrays<float> f32;
+    DeviceArrays<double> f64;
+    DNode *nodes = nullptr;
+    DCsg *csgs = nullptr;
+    uint32_t *leaf_orig = nullptr;
+    DScene<float> h32;
+    DScene<double> h64;
+    int num_cu = 256;
+};
+
+static bool is_csg_kind(int k) { return k >= RTMI_NODE_CSG_UNION && k <= RTMI_NODE_CSG_DIFFERENCE; }
+
+struct Layout {
+    const rtmi_scene_desc *d;
+    std::vector<uint32_t> leaf_orig;   // device leaf -> desc leaf
+    std::vector<uint32_t> leaf_csg;    // device leaf -> innermost CSG operator
+    std::vector<uint8_t> leaf_shadow;  // device leaf -> casts shadows
+    std::vector<DNode> nodes;
+    std::vector<DCsg> csgs;
+    std::string err;
+    int err_code = RTMI_OK;
+    std::vector<uint8_t> seen_leaf, seen_node;
+
+    bool bad(int code, const std::string &m) { if (err_code == RTMI_OK) { err_code = code; err = m; } return false; }
+
+    bool check_node(int n) {
+        if (n < 0 || n >= d->n_nodes) return bad(RTMI_ERR_INVALID, "node index out of range");
+        if (seen_node[n]) return bad(RTMI_ERR_INVALID, "node referenced twice (the scene must be a tree)");
+        seen_node[n] = 1;
+        return true;
+    }
+
+    void push_leaf(int desc_leaf, uint32_t csg, bool shadow) {
+        if (desc_leaf < 0 || desc_leaf >= d->n_leaves) { bad(RTMI_ERR_INVALID, "leaf index out of range"); return; }
+        if (seen_leaf[desc_leaf]) { bad(RTMI_ERR_INVALID, "leaf referenced twice"); return; }
+        seen_leaf[desc_leaf] = 1;
+        leaf_orig.push_back((uint32_t)desc_leaf);
+        leaf_csg.push_back(csg);
+        leaf_shadow.push_back(shadow ? 1 : 0);
+    }
+
+    // conservative f32 box around the host's f64 box; returns false if the box cannot be used as a gate
+    static bool make_box(const rtmi_node &n, DNode &o) {
+        for (int a = 0; a < 3; ++a) {
+            double lo = n.aabb_min[a], hi = n.aabb_max[a];
+            if (!std::isfinite(lo) || !std::isfinite(hi) || lo > hi) return false;
+            double pad = 1e-5 * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo) + 1e-6;
+            float flo = (float)(lo - pad), fhi = (float)(hi + pad);
+            if ((double)flo > lo - pad) flo = std::nextafterf(flo, -INFINITY);
+            if ((double)fhi < hi + pad) fhi = std::nextafterf(fhi, INFINITY);
+            o.bmin[a] = flo; o.bmax[a] = fhi;
+        }
+        return true;
+    }
+
+    // leaves below a CSG operator side; Groups are transparent to the filter (csg.rs:102, contains())
+    void csg_side(int n, uint32_t parent, bool shadow, uint32_t &bit_counter) {
+        if (!check_node(n)) return;
+        const rtmi_node &nd = d->nodes[n];
+        if (nd.kind == RTMI_NODE_LEAF) { push_leaf(nd.first, parent, shadow); return; }
+        if (nd.kind == RTMI_NODE_GROUP || nd.kind == RTMI_NODE_BOUNDED) {
+            if (nd.first < 0 || nd.count < 0 || nd.first + nd.count > d->n_children) { bad(RTMI_ERR_INVALID, "children range out of bounds"); return; }
+            for (int i = 0; i < nd.count; ++i) csg_side(d->children[nd.first + i], parent, shadow, bit_counter);
+            return;
+        }
+        if (!is_csg_kind(nd.kind)) { bad(RTMI_ERR_INVALID, "bad node kind"); return; }
+        csg_op(n, parent, shadow, bit_counter);
+    }
+    void csg_op(int n, uint32_t parent, bool shadow, uint32_t &bit_counter) {
+        const rtmi_node &nd = d->nodes[n];
+        uint32_t me = (uint32_t)csgs.size();
+        DCsg c;
+        c.op = (uint32_t)nd.kind; c.left_end = 0; c.parent = parent; c.bit = bit_counter++;
+        csgs.push_back(c);
+        csg_side(nd.first, me, shadow, bit_counter);
+        csgs[me].left_end = (uint32_t)leaf_orig.size();
+        csg_side(nd.count, me, shadow, bit_counter);
+    }
+
+    // fill device node `slot` from desc node n (a GROUP/BOUNDED or a CSG root)
+    void fill(uint32_t slot, int n, bool shadow) {
+        if (!check_node(n)) return;
+        const rtmi_node &nd = d->nodes[n];
+        DNode o;
+        memset(&o, 0, sizeof o);
+        o.flags = shadow ? NODE_CAST_SHADOW : 0;
+        if (make_box(nd, o)) o.flags |= NODE_GATED;
+        if (is_csg_kind(nd.kind)) {
+            o.flags |= NODE_CSGROOT;
+            o.leaf_first = (uint32_t)leaf_orig.size();
+            uint32_t bits = 0;
+            csg_op(n, NONE, shadow, bits);
+            o.leaf_count = (uint32_t)leaf_orig.size() - o.leaf_first;
+            o.csg_count = bits;
+            if (bits > (uint32_t)CSG_MAX_NODES)
+                bad(RTMI_ERR_UNSUPPORTED, "more than " + std::to_string(CSG_MAX_NODES) + " CSG operators under one CSG root");
+            nodes[slot] = o;
+            return;
+        }
+        if (nd.kind != RTMI_NODE_GROUP && nd.kind != RTMI_NODE_BOUNDED) { bad(RTMI_ERR_INVALID, "bad node kind"); return; }
+        if (nd.first < 0 || nd.count < 0 || nd.first + nd.count > d->n_children) { bad(RTMI_ERR_INVALID, "children range out of bounds"); return; }
+        std::vector<int> kids(d->children + nd.first, d->children + nd.first + nd.count);
+        inner(slot, o, kids, std::vector<uint8_t>(kids.size(), shadow ? 1 : 0));
+    }
+
+    // direct primitive children first (contiguous leaves), then contiguous slots for the inner children
+    void inner(uint32_t slot, DNode o, const std::vector<int> &kids, const std::vector<uint8_t> &shadow) {
+        o.leaf_first = (uint32_t)leaf_orig.size();
+        std::vector<std::pair<int, uint8_t>> sub;
+        for (size_t i = 0; i < kids.size(); ++i) {
+            int k = kids[i];
+            if (k < 0 || k >= d->n_nodes) { bad(RTMI_ERR_INVALID, "node index out of range"); return; }
+            if (d->nodes[k].kind == RTMI_NODE_LEAF) {
+                if (!check_node(k)) return;
+                push_leaf(d->nodes[k].first, NONE, shadow[i]);
+            } else {
+                sub.push_back({k, shadow[i]});
+            }
+        }
+        o.leaf_count = (uint32_t)leaf_orig.size() - o.leaf_first;
+        o.child_first = (uint32_t)nodes.size();
+        o.child_count = (uint32_t)sub.size();
+        nodes.resize(nodes.size() + sub.size());
+        nodes[slot] = o;
+        for (size_t i = 0; i < sub.size(); ++i) fill(o.child_first + (uint32_t)i, sub[i].first, sub[i].second != 0);
+    }
+
+    // worst-case number of traversal-stack entries in use while the subtree of device node `slot` is processed:
+    // its k children are pushed together and popped first child first, so k - 1 - i siblings wait below child i
+    int stack_need(uint32_t slot) const {
+        const DNode &o = nodes[slot];
+        if (o.flags & NODE_CSGROOT) return 0;
+        int need = (int)o.child_count;
+        for (uint32_t i = 0; i < o.child_count; ++i)
+            need = std::max(need, (int)(o.child_count - 1 - i) + stack_need(o.child_first + i));
+        return need;
+    }
+
+    bool run() {
+        seen_leaf.assign((size_t)std::max(0, d->n_leaves), 0);
+        seen_node.assign((size_t)std::max(0, d->n_nodes), 0);
+        nodes.resize(1); // slot 0 = virtual root = World::objects
+        DNode root;
+        memset(&root, 0, sizeof root);
+        root.flags = NODE_CAST_SHADOW;
+        std::vector<int> kids(d->top_nodes, d->top_nodes + d->n_top);
+        std::vector<uint8_t> sh((size_t)d->n_top);
+        for (int i = 0; i < d->n_top; ++i) sh[(size_t)i] = d->top_cast_shadow ? (d->top_cast_shadow[i] ? 1 : 0) : 1;
+        inner(0, root, kids, sh);
+        if (err_code != RTMI_OK) return false;
+        if (stack_need(0) > NODE_STACK) return bad(RTMI_ERR_UNSUPPORTED, "scene tree needs a deeper traversal stack than " + std::to_string(NODE_STACK));
+        return true;
+    }
+};
+
+template <typename R> static void cp3(R *dst, const double *src) { dst[0] = (R)src[0]; dst[1] = (R)src[1]; dst[2] = (R)src[2]; }
+template <typename R> static void cp12(R *dst, const double *src) { for (int i = 0; i < 12; ++i) dst[i] = (R)src[i]; }
+
+template <typename T> static int upload(T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RTMI_OK;
+}
+
+template <typename R>
+static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A) {
+    std::vector<DLeaf<R>> leaves(L.leaf_orig.size());
+    std::vector<DTri<R>> tris;
+    for (size_t i = 0; i < leaves.size(); ++i) {
+        const rtmi_leaf &s = d->leaves[L.leaf_orig[i]];
+        DLeaf<R> &g = leaves[i];
+        memset(&g, 0, sizeof g);
+        cp12(g.inv, s.inv);
+        g.minimum = (R)s.minimum; g.maximum = (R)s.maximum;
+        g.kind = (uint32_t)s.kind | (s.closed ? LEAF_CLOSED : 0u) | (L.leaf_shadow[i] ? LEAF_CAST_SHADOW : 0u);
+        g.material = (uint32_t)s.material;
+        g.csg_parent = L.leaf_csg[i];
+        g.tri = 0;
+        if (s.kind == RTMI_TRIANGLE || s.kind == RTMI_SMOOTH_TRIANGLE) {
+            DTri<R> t;
+            double e1[3], e2[3];
+            for (int a = 0; a < 3; ++a) { e1[a] = s.p2[a] - s.p1[a]; e2[a] = s.p3[a] - s.p1[a]; } // triangle.rs:35-36
+            cp3(t.p1, s.p1); cp3(t.e1, e1); cp3(t.e2, e2);
+            if (s.kind == RTMI_SMOOTH_TRIANGLE) { cp3(t.n1, s.n1); cp3(t.n2, s.n2); cp3(t.n3, s.n3); }
+            else { // normal = normalize(e2 x e1), triangle.rs:43
+                double nx = e2[1] * e1[2] - e2[2] * e1[1], ny = e2[2] * e1[0] - e2[0] * e1[2], nz = e2[0] * e1[1] - e2[1] * e1[0];
+                double inv = 1.0 / std::sqrt(nx * nx + ny * ny + nz * nz);
+                double nn[3] = {nx * inv, ny * inv, nz * inv};
+                cp3(t.n1, nn); cp3(t.n2, nn); cp3(t.n3, nn);
+            }
+            g.tri = (uint32_t)tris.size();
+            tris.push_back(t);
+        }
+    }
+    std::vector<DMaterial<R>> mats((size_t)d->n_materials);
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rtmi_material &s = d->materials[i];
+        DMaterial<R> &m = mats[(size_t)i];
+        memset(&m, 0, sizeof m);
+        cp3(m.color, s.color);
+        m.emissive = (R)s.emissive; m.diffuse = (R)s.diffuse; m.specular = (R)s.specular; m.shininess = (R)s.shininess;
+        m.reflective = (R)s.reflective; m.transparency = (R)s.transparency; m.ior = (R)s.refractive_index;
+        m.pattern = s.pattern;
+    }
+    std::vector<DPattern<R>> pats((size_t)d->n_patterns);
+    for (int i = 0; i < d->n_patterns; ++i) {
+        const rtmi_pattern &s = d->patterns[i];
+        DPattern<R> &p = pats[(size_t)i];
+        memset(&p, 0, sizeof p);
+        cp12(p.inv, s.inv); cp3(p.a, s.a); cp3(p.b, s.b);
+        p.kind = s.kind;
+    }
+    std::vector<DLight<R>> lights((size_t)d->n_lights);
+    for (int i = 0; i < d->n_lights; ++i) {
+        const rtmi_light &s = d->lights[i];
+        DLight<R> &l = lights[(size_t)i];
+        memset(&l, 0, sizeof l);
+        cp3(l.pos, s.position); cp3(l.intensity, s.intensity);
+        l.radius = (R)s.radius;
+        cp3(l.normal, s.normal); cp3(l.width, s.width); cp3(l.height, s.height);
+        cp3(l.up, s.up); cp3(l.right, s.right); cp3(l.dir, s.direction);
+        double u2 = s.up[0] * s.up[0] + s.up[1] * s.up[1] + s.up[2] * s.up[2];
+        double r2 = s.right[0] * s.right[0] + s.right[1] * s.right[1] + s.right[2] * s.right[2];
+        l.inv_up2 = (R)(u2 > 0 ? 1.0 / u2 : 0.0); l.inv_right2 = (R)(r2 > 0 ? 1.0 / r2 : 0.0);
+        l.kind = s.kind;
+    }
+    int rc;
+    if ((rc = upload(&A.leaves, leaves)) != RTMI_OK) return rc;
+    if ((rc = upload(&A.tris, tris)) != RTMI_OK) return rc;
+    if ((rc = upload(&A.materials, mats)) != RTMI_OK) return rc;
+    if ((rc = upload(&A.patterns, pats)) != RTMI_OK) return rc;
+    if ((rc = upload(&A.lights, lights)) != RTMI_OK) return rc;
+    return RTMI_OK;
+}
+
+template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_desc *d, const Layout &L, const DeviceArrays<R> &A, DScene<R> &h) {
+    h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
+    h.nodes = s->nodes; h.csgs = s->csgs; h.leaf_orig = s->leaf_orig;
+    h.n_leaves = (uint32_t)L.leaf_orig.size(); h.n_lights = (uint32_t)d->n_lights; h.n_nodes = (uint32_t)L.nodes.size();
+    h.max_depth = (uint32_t)d->max_depth;
+    h.root_leaf_count = L.nodes[0].leaf_count; h.root_child_first = L.nodes[0].child_first; h.root_child_count = L.nodes[0].child_count;
+    h.pad = 0;
+}
+
+static int validate(const rtmi_scene_desc *d) {
+    if (!d) return fail(RTMI_ERR_INVALID, "null scene descriptor");
+    if (d->abi_version != RTMI_ABI_VERSION) return fail(RTMI_ERR_INVALID, "abi_version mismatch");
+    if (d->n_leaves < 0 || d->n_nodes < 0 || d->n_children < 0 || d->n_top < 0 || d->n_materials < 0 || d->n_patterns < 0 || d->n_lights < 0)
+        return fail(RTMI_ERR_INVALID, "negative count");
+    if ((d->n_leaves && !d->leaves) || (d->n_nodes && !d->nodes) || (d->n_children && !d->children) || (d->n_top && !d->top_nodes) ||
+        (d->n_materials && !d->materials) || (d->n_patterns && !d->patterns) || (d->n_lights && !d->lights))
+        return fail(RTMI_ERR_INVALID, "null array with non-zero count");
+    if (d->max_depth < 0 || d->max_depth > MAX_DEPTH)
+        return fail(RTMI_ERR_UNSUPPORTED, "max_depth must be in [0, " + std::to_string(MAX_DEPTH) + "]");
+    if ((unsigned)d->n_leaves > ID_LEAF_MASK) return fail(RTMI_ERR_UNSUPPORTED, "too many leaves");
+    for (int i = 0; i < d->n_leaves; ++i) {
+        const rtmi_leaf &l = d->leaves[i];
+        if (l.kind < RTMI_SPHERE || l.kind > RTMI_SMOOTH_TRIANGLE) return fail(RTMI_ERR_INVALID, "leaf " + std::to_string(i) + ": bad kind");
+        if (l.material < 0 || l.material >= d->n_materials) return fail(RTMI_ERR_INVALID, "leaf " + std::to_string(i) + ": material out of range");
+    }
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].pattern >= d->n_patterns) return fail(RTMI_ERR_INVALID, "material " + std::to_string(i) + ": pattern out of range");
+    for (int i = 0; i < d->n_patterns; ++i)
+        if (d->patterns[i].kind < RTMI_PATTERN_STRIPE || d->patterns[i].kind > RTMI_PATTERN_XYZ)
+            return fail(RTMI_ERR_INVALID, "pattern " + std::to_string(i) + ": bad kind (closures cannot cross the ABI)");
+    for (int i = 0; i < d->n_lights; ++i)
+        if (d->lights[i].kind < RTMI_LIGHT_POINT || d->lights[i].kind > RTMI_LIGHT_BEAM) return fail(RTMI_ERR_INVALID, "light " + std::to_string(i) + ": bad kind");
+    return RTMI_OK;
+}
+
+static int ensure_device(int *dev) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    HIP_TRY(hipGetDevice(dev));
+    return RTMI_OK;
+}
+
+extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
+    if (!s) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
+    (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
+    (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig);
+    if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
+    delete s;
+}
+
+extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) {
+    if (!out) return fail(RTMI_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int rc = validate(desc);
+    if (rc != RTMI_OK) return rc;
+    Layout L;
+    L.d = desc;
+    if (!L.run()) return fail(L.err_code, L.err);
+    int dev = 0;
+    if ((rc = ensure_device(&dev)) != RTMI_OK) return rc;
+    rtmi_scene *s = new rtmi_scene();
+    s->device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) s->num_cu = prop.multiProcessorCount;
+    rc = upload(&s->nodes, L.nodes);
+    if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
+    if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
+    if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32);
+    if (rc == RTMI_OK) rc = upload_typed<double>(desc, L, s->f64);
+    if (rc != RTMI_OK) { rtmi_scene_destroy(s); return rc; }
+    header(s, desc, L, s->f32, s->h32);
+    header(s, desc, L, s->f64, s->h64);
+    *out = s;
+    return RTMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: launches
+// ---------------------------------------------------------------------------------------------
+static int norm_tile_rows(int tile_rows) {
+    if (tile_rows <= 0) return 8;
+    return ((tile_rows + 7) / 8) * 8;
+}
+
+extern "C" int32_t rtmi_rank_rows(int32_t vsize, int32_t rank, int32_t nranks, int32_t tile_rows) {
+    if (nranks <= 1) return vsize > 0 ? vsize : 0;
+    if (rank < 0 || rank >= nranks || vsize <= 0) return 0;
+    int tr = norm_tile_rows(tile_rows);
+    int n_tiles = (vsize + tr - 1) / tr, rows = 0;
+    for (int t = rank; t < n_tiles; t += nranks) rows += std::min(tr, vsize - t * tr);
+    return rows;
+}
+
+template <typename R> static DCamera<R> make_camera(const rtmi_camera *c, const rtmi_render_opts *o) {
+    DCamera<R> k;
+    cp12(k.inv, c->inv);
+    k.pixel_size = (R)c->pixel_size; k.half_width = (R)c->half_width; k.half_height = (R)c->half_height;
+    k.se2 = (R)(c->allowed_standard_error * c->allowed_standard_error);
+    k.focal_distance = (R)c->focal_distance; k.aperture_size = (R)c->aperture_size;
+    k.hsize = c->hsize; k.vsize = c->vsize; k.min_samples = c->min_samples; k.max_samples = o ? o->max_samples : 0;
+    return k;
+}
+
+static int check_camera(const rtmi_camera *c) {
+    if (!c) return fail(RTMI_ERR_INVALID, "null camera");
+    if (c->hsize <= 0 || c->vsize <= 0 || (long long)c->hsize * c->vsize > 0x7FFFFFFFll) return fail(RTMI_ERR_INVALID, "bad camera size");
+    if (!(c->pixel_size > 0)) return fail(RTMI_ERR_INVALID, "bad pixel_size");
+    return RTMI_OK;
+}
+
+static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st) {
+    int rank = 0, nranks = 1, tr = 8;
+    if (o && o->nranks > 1) {
+        nranks = o->nranks; rank = o->rank; tr = norm_tile_rows(o->tile_rows);
+        if (rank < 0 || rank >= nranks) return fail(RTMI_ERR_INVALID, "rank out of range");
+    }
+    int rows = rtmi_rank_rows(c->vsize, rank, nranks, tr);
+    if (rows == 0) return RTMI_OK;
+    DRender rp;
+    uint64_t seed = o ? o->seed : 0;
+    rp.seed_lo = (uint32_t)seed; rp.seed_hi = (uint32_t)(seed >> 32);
+    rp.rank = rank; rp.nranks = nranks; rp.tile_rows = tr;
+    rp.tiles_x = (c->hsize + 7) / 8;
+    rp.local_tile_rows8 = (rows + 7) / 8;
+    rp.n_tiles = rp.tiles_x * rp.local_tile_rows8;
+    int grid = std::min(rp.n_tiles, s->num_cu * 32);
+    bool f64 = o && o->precision == RTMI_PRECISION_F64;
+    if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
+    if (f64) hipLaunchKernelGGL(render_kernel<double>, dim3(grid), dim3(64), 0, st, s->h64, make_camera<double>(c, o), rp, d_out, (unsigned long long *)d_stats);
+    else hipLaunchKernelGGL(render_kernel<float>, dim3(grid), dim3(64), 0, st, s->h32, make_camera<float>(c, o), rp, d_out, (unsigned long long *)d_stats);
+    HIP_TRY(hipGetLastError());
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *d_rgb_out,
+                                  uint64_t *d_stats, void *hip_stream) {
+    if (!scene || !d_rgb_out) return fail(RTMI_ERR_INVALID, "null scene or output");
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    return launch_render(scene, camera, opts, d_rgb_out, d_stats, (hipStream_t)hip_stream);
+}
+
+extern "C" int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *rgb_out, rtmi_stats *stats_out) {
+    if (!scene || !rgb_out) return fail(RTMI_ERR_INVALID, "null scene or output");
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    rtmi_render_opts o;
+    memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    o.rank = 0; o.nranks = 1;
+    size_t n = (size_t)camera->hsize * camera->vsize * 3;
+    float *d_out = nullptr;
+    uint64_t *d_stats = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, n * sizeof(float)));
+    rc = RTMI_OK;
+    auto cleanup = [&]() { (void)hipFree(d_out); (void)hipFree(d_stats); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+#define TRY_OR_CLEAN(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) { cleanup(); return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void **)&d_stats, RTMI_N_STATS * sizeof(uint64_t)));
+    TRY_OR_CLEAN(hipMemset(d_stats, 0, RTMI_N_STATS * sizeof(uint64_t)));
+    TRY_OR_CLEAN(hipEventCreate(&e0));
+    TRY_OR_CLEAN(hipEventCreate(&e1));
+    TRY_OR_CLEAN(hipEventRecord(e0, 0));
+    rc = launch_render(scene, camera, &o, d_out, d_stats, 0);
+    if (rc != RTMI_OK) { cleanup(); return rc; }
+    TRY_OR_CLEAN(hipEventRecord(e1, 0));
+    TRY_OR_CLEAN(hipEventSynchronize(e1));
+    TRY_OR_CLEAN(hipMemcpy(rgb_out, d_out, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats_out) {
+        memset(stats_out, 0, sizeof *stats_out);
+        TRY_OR_CLEAN(hipMemcpy(stats_out->counter, d_stats, RTMI_N_STATS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        float ms = 0;
+        TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+        stats_out->kernel_ms = ms;
+    }
+    cleanup();
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_tonemap_u8_device(const float *d_rgb, uint8_t *d_rgb8, int64_t n_values, void *hip_stream) {
+    if (!d_rgb || !d_rgb8 || n_values < 0) return fail(RTMI_ERR_INVALID, "bad tonemap arguments");
+    if (n_values == 0) return RTMI_OK;
+    long long threads = (n_values + 3) / 4;
+    int grid = (int)((threads + 255) / 256);
+    hipLaunchKernelGGL(tonemap_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_rgb, d_rgb8, (long long)n_values);
+    HIP_TRY(hipGetLastError());
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_trace_rays(const rtmi_scene *scene, const rtmi_render_opts *opts, int64_t n, const double *origins, const double *directions,
+                               const int32_t *remaining, double *rgb_out, rtmi_hit_record *hits_out) {
+    if (!scene || !origins || !directions || n < 0) return fail(RTMI_ERR_INVALID, "bad trace arguments");
+    if (n == 0) return RTMI_OK;
+    double *d_o = nullptr, *d_d = nullptr, *d_rgb = nullptr;
+    int *d_rem = nullptr;
+    rtmi_hit_record *d_rec = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_rgb); (void)hipFree(d_rem); (void)hipFree(d_rec); };
+    size_t b3 = (size_t)n * 3 * sizeof(double);
+    TRY_OR_CLEAN(hipMalloc((void **)&d_o, b3));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_d, b3));
+    TRY_OR_CLEAN(hipMemcpy(d_o, origins, b3, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(d_d, directions, b3, hipMemcpyHostToDevice));
+    if (remaining) {
+        TRY_OR_CLEAN(hipMalloc((void **)&d_rem, (size_t)n * sizeof(int)));
+        TRY_OR_CLEAN(hipMemcpy(d_rem, remaining, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (rgb_out) TRY_OR_CLEAN(hipMalloc((void **)&d_rgb, b3));
+    if (hits_out) TRY_OR_CLEAN(hipMalloc((void **)&d_rec, (size_t)n * sizeof(rtmi_hit_record)));
+    uint64_t seed = opts ? opts->seed : 0;
+    bool f64 = opts && opts->precision == RTMI_PRECISION_F64;
+    int grid = (int)((n + 63) / 64);
+    if (f64) hipLaunchKernelGGL(trace_kernel<double>, dim3(grid), dim3(64), 0, 0, scene->h64, (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_o, d_d, d_rem, d_rgb, d_rec);
+    else hipLaunchKernelGGL(trace_kernel<float>, dim3(grid), dim3(64), 0, 0, scene->h32, (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_o, d_d, d_rem, d_rgb, d_rec);
+    TRY_OR_CLEAN(hipGetLastError());
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    if (rgb_out) TRY_OR_CLEAN(hipMemcpy(rgb_out, d_rgb, b3, hipMemcpyDeviceToHost));
+    if (hits_out) TRY_OR_CLEAN(hipMemcpy(hits_out, d_rec, (size_t)n * sizeof(rtmi_hit_record), hipMemcpyDeviceToHost));
+    cleanup();
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_camera_rays(const rtmi_camera *camera, const rtmi_render_opts *opts, int64_t n, const int32_t *px, const int32_t *py,
+                                const int32_t *sample, double *origins_out, double *directions_out) {
+    if (!px || !py || !origins_out || !directions_out || n < 0) return fail(RTMI_ERR_INVALID, "bad camera_rays arguments");
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    if (n == 0) return RTMI_OK;
+    int dev;
+    if ((rc = ensure_device(&dev)) != RTMI_OK) return rc;
+    int *d_px = nullptr, *d_py = nullptr, *d_s = nullptr;
+    double *d_o = nullptr, *d_d = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_px); (void)hipFree(d_py); (void)hipFree(d_s); (void)hipFree(d_o); (void)hipFree(d_d); };
+    size_t bi = (size_t)n * sizeof(int), b3 = (size_t)n * 3 * sizeof(double);
+    TRY_OR_CLEAN(hipMalloc((void **)&d_px, bi));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_py, bi));
+    TRY_OR_CLEAN(hipMemcpy(d_px, px, bi, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(d_py, py, bi, hipMemcpyHostToDevice));
+    if (sample) {
+        TRY_OR_CLEAN(hipMalloc((void **)&d_s, bi));
+        TRY_OR_CLEAN(hipMemcpy(d_s, sample, bi, hipMemcpyHostToDevice));
+    }
+    TRY_OR_CLEAN(hipMalloc((void **)&d_o, b3));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_d, b3));
+    uint64_t seed = opts ? opts->seed : 0;
+    bool f64 = opts && opts->precision == RTMI_PRECISION_F64;
+    int grid = (int)((n + 255) / 256);
+    if (f64) hipLaunchKernelGGL(camera_rays_kernel<double>, dim3(grid), dim3(256), 0, 0, make_camera<double>(camera, opts), (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_px, d_py, d_s, d_o, d_d);
+    else hipLaunchKernelGGL(camera_rays_kernel<float>, dim3(grid), dim3(256), 0, 0, make_camera<float>(camera, opts), (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_px, d_py, d_s, d_o, d_d);
+    TRY_OR_CLEAN(hipGetLastError());
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    TRY_OR_CLEAN(hipMemcpy(origins_out, d_o, b3, hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(directions_out, d_d, b3, hipMemcpyDeviceToHost));
+    cleanup();
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_describe(char *buf, int32_t buf_len) {
+    if (!buf || buf_len <= 0) return fail(RTMI_ERR_INVALID, "bad buffer");
+    int n = 0;
+    std::string dev = "no device";
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 0) {
+        int d = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess)
+            dev = std::string(p.name) + " " + p.gcnArchName + " CUs=" + std::to_string(p.multiProcessorCount) + " clock_khz=" + std::to_string(p.clockRate);
+    }
+    snprintf(buf, (size_t)buf_len, "rtmi abi=%d target=gfx950 devices=%d [%s]", RTMI_ABI_VERSION, n, dev.c_str());
+    return RTMI_OK;
+}

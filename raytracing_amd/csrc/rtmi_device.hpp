@@ -1,0 +1,876 @@
+// rtmi_device.hpp — device-side ray casting for gfx950 (MI355X), templated on the arithmetic type.
+//
+// One lane = one pixel-sample stream; one wave64 = one 8x8 pixel tile.  The path is FP32 VALU- and
+// divergence-bound (no MFMA).  R = float is the product path; R = double is a validation mode that
+// reproduces the f64 oracle almost bit for bit.
+//
+// Reference semantics restated here (paths relative to rust/src/):
+//   camera.rs:120-153,273-310   ray_for_pixel, multisample, color_variance_of_mean
+//   world.rs:111-180            trace / color_at / intersect / intersect_shadow / is_shadowed
+//   ray.rs:72-140,143-154,199-219  prepare_computations, n1/n2 container walk, hit, schlick
+//   materials.rs:239-336,371-412   color_at, lighting, reflected_color, refracted_color, shade_hit
+//   lights.rs                   incoming_at for all six light kinds
+//   shapes/{sphere,plane,cube,cylinder,cone,triangle,csg}.rs  local_intersect + normal_at
+//   shapes/mod.rs:252-265,319-322,399-405,471-477  ray/normal transforms, Group, BoundingGroup
+//   aabb.rs:45-70               slab test          pattern.rs:7-35   the four patterns
+//
+// What is deliberately NOT like the reference (same results, different machine):
+//   * no intersection lists: closest hit = running minimum over t >= 0; shadow = any hit in
+//     [0, dist); the n1/n2 container walk becomes an order-free "open leaf with the latest entry"
+//     search (see collect_n1n2);
+//   * CSG trees are evaluated per root from one small sorted buffer with a bit-mask of in/out states,
+//     walking each leaf's chain of CSG ancestors (csg.rs:97-112 applied bottom-up);
+//   * recursion (materials.rs:290-336) is a loop with a bounded stack of pending refraction rays;
+//   * a ray spawned on leaf L never re-hits L at its own starting point: L's root nearest to zero is
+//     classified "behind" analytically instead of trusting the sign of a +-1e-5 quantity in f32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtmi.h"
+
+namespace rtmi_dev {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int MAX_DEPTH = 16;      // bound of the pending-ray stack (scene max_depth must be <= this)
+constexpr int NODE_STACK = 64;     // traversal stack entries per lane
+constexpr int CSG_BUF = 48;        // intersections buffered per CSG root and lane
+constexpr int CSG_MAX_NODES = 32;  // CSG operator nodes under one root (2 state bits each in a u64)
+
+// leaf.kind bit layout
+constexpr uint32_t LEAF_KIND_MASK = 0xFFu;
+constexpr uint32_t LEAF_CLOSED = 1u << 8;
+constexpr uint32_t LEAF_CAST_SHADOW = 1u << 9;
+
+// node.flags
+constexpr uint32_t NODE_CSGROOT = 1u << 0;
+constexpr uint32_t NODE_GATED = 1u << 1;       // box is finite and proper: may be slab-tested
+constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
+
+template <typename R> struct DLeaf {
+    R inv[12];           // rows 0..2 of the world->object matrix
+    R minimum, maximum;  // cylinder / cone
+    uint32_t kind;       // kind | LEAF_CLOSED | LEAF_CAST_SHADOW
+    uint32_t material;
+    uint32_t tri;        // index into tris (triangle kinds)
+    uint32_t csg_parent; // innermost enclosing CSG operator, or NONE
+    uint32_t pad[2];
+};
+
+template <typename R> struct DTri {
+    R p1[3], e1[3], e2[3]; // triangle.rs:33-45
+    R n1[3], n2[3], n3[3]; // flat triangles store normalize(e2 x e1) three times
+};
+
+template <typename R> struct DMaterial {
+    R color[3];
+    R emissive, diffuse, specular, shininess, reflective, transparency, ior;
+    int32_t pattern;
+    uint32_t pad;
+};
+
+template <typename R> struct DPattern {
+    R inv[12];
+    R a[3], b[3];
+    int32_t kind;
+    uint32_t pad;
+};
+
+template <typename R> struct DLight {
+    R pos[3], intensity[3];
+    R radius;
+    R normal[3], width[3], height[3];
+    R up[3], right[3], dir[3];
+    R inv_up2, inv_right2;
+    int32_t kind;
+    uint32_t pad;
+};
+
+struct DNode { // 48 B
+    float bmin[3];
+    uint32_t leaf_first;
+    float bmax[3];
+    uint32_t leaf_count;
+    uint32_t child_first, child_count;
+    uint32_t flags;
+    uint32_t csg_count; // CSGROOT: number of CSG operator nodes below (state bits used)
+};
+
+struct DCsg { // 16 B
+    uint32_t op;       // RTMI_NODE_CSG_*
+    uint32_t left_end; // leaves of this operator with index < left_end belong to its left child
+    uint32_t parent;   // enclosing CSG operator or NONE
+    uint32_t bit;      // index of this operator under its root (state bits 2*bit, 2*bit+1)
+};
+
+template <typename R> struct DScene {
+    const DLeaf<R> *leaves;
+    const DTri<R> *tris;
+    const DMaterial<R> *materials;
+    const DPattern<R> *patterns;
+    const DLight<R> *lights;
+    const DNode *nodes;
+    const DCsg *csgs;
+    const uint32_t *leaf_orig; // device leaf -> index in rtmi_scene_desc.leaves
+    uint32_t n_leaves, n_lights, n_nodes, max_depth;
+    uint32_t root_leaf_count, root_child_first, root_child_count, pad;
+};
+
+template <typename R> struct DCamera {
+    R inv[12];
+    R pixel_size, half_width, half_height, se2, focal_distance, aperture_size;
+    int32_t hsize, vsize, min_samples, max_samples;
+};
+
+struct DRender {
+    uint32_t seed_lo, seed_hi;
+    int32_t rank, nranks, tile_rows;
+    int32_t tiles_x, local_tile_rows8; // 8-row tile rows owned by this rank
+    int32_t n_tiles;
+};
+
+// ---------------------------------------------------------------------------------------------
+// small vector algebra
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct V3 { R x, y, z; };
+template <typename R> __device__ __forceinline__ V3<R> mk(R x, R y, R z) { return {x, y, z}; }
+template <typename R> __device__ __forceinline__ V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename R> __device__ __forceinline__ V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename R> __device__ __forceinline__ V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <typename R> __device__ __forceinline__ V3<R> operator*(V3<R> a, R s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename R> __device__ __forceinline__ V3<R> had(V3<R> a, V3<R> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float abs_(float x) { return fabsf(x); }
+__device__ __forceinline__ double abs_(double x) { return fabs(x); }
+__device__ __forceinline__ float min_(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double min_(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float max_(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float floor_(float x) { return floorf(x); }
+__device__ __forceinline__ double floor_(double x) { return floor(x); }
+// tuple.rs:118 normalises by multiplying with the inverse length
+template <typename R> __device__ __forceinline__ V3<R> normalize(V3<R> a) { return a * rsqrt_(dot(a, a)); }
+template <typename R> __device__ __forceinline__ V3<R> ld3(const R *p) { return {p[0], p[1], p[2]}; }
+
+// rows 0..2 of M times a point (w = 1) / a vector (w = 0) / M^T times a vector (matrix.rs:311-345)
+template <typename R> __device__ __forceinline__ V3<R> xf_point(const R *m, V3<R> p) {
+    return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+template <typename R> __device__ __forceinline__ V3<R> xf_vector(const R *m, V3<R> p) {
+    return {m[0] * p.x + m[1] * p.y + m[2] * p.z, m[4] * p.x + m[5] * p.y + m[6] * p.z, m[8] * p.x + m[9] * p.y + m[10] * p.z};
+}
+template <typename R> __device__ __forceinline__ V3<R> xf_normal(const R *m, V3<R> p) {
+    return {m[0] * p.x + m[4] * p.y + m[8] * p.z, m[1] * p.x + m[5] * p.y + m[9] * p.z, m[2] * p.x + m[6] * p.y + m[10] * p.z};
+}
+
+template <typename R> struct Ray { V3<R> o, d; };
+
+template <typename R> struct Lim;
+template <> struct Lim<float> { static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); } };
+template <> struct Lim<double> { static __device__ __forceinline__ double inf() { return __builtin_huge_val(); } };
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG: Philox4x32-10, counter = (pixel, sample, draw/4, tag), key = seed.
+// The oracle (oracle/rt_oracle.c: orc_philox / orc_uniform) runs the identical integer code, so both
+// sides draw identical 24-bit uniforms.
+// ---------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t k0, k1, pixel, sample, draw;
+    uint32_t cache[4];
+    uint32_t cached_block;
+};
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void rng_begin(Rng &g, uint32_t pixel, uint32_t sample) {
+    g.pixel = pixel; g.sample = sample; g.draw = 0; g.cached_block = NONE;
+}
+template <typename R> __device__ __forceinline__ R rng_next(Rng &g) {
+    uint32_t blk = g.draw >> 2;
+    if (blk != g.cached_block) {
+        philox4x32_10(g.k0, g.k1, g.pixel, g.sample, blk, 0x52544D49u, g.cache);
+        g.cached_block = blk;
+    }
+    uint32_t lane = g.draw & 3u;
+    uint32_t v = lane == 0 ? g.cache[0] : lane == 1 ? g.cache[1] : lane == 2 ? g.cache[2] : g.cache[3];
+    g.draw++;
+    return (R)(v >> 8) * (R)(1.0 / 16777216.0);
+}
+
+struct Stats {
+    uint32_t c[RTMI_N_STATS];
+};
+
+// ---------------------------------------------------------------------------------------------
+// local_intersect per primitive kind (object space).  Roots come back ascending in t[0..n).
+// ---------------------------------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ void cswap(R &a, R &b) { R lo = min_(a, b), hi = max_(a, b); a = lo; b = hi; }
+
+// Roots of a t^2 + 2 hb t + c = 0 given disc4 = hb^2 - a c >= 0.
+// double: literally the reference's expressions (sphere.rs:59-60, cylinder.rs:94,100).
+// float : the cancellation-free form q = -(hb + sign(hb) sqrt(disc4)); roots q/a and c/q.
+__device__ __forceinline__ void quad_roots(double a, double hb, double c, double disc4, double &t0, double &t1) {
+    (void)c;
+    double b = 2.0 * hb, sq = sqrt(4.0 * disc4);
+    t0 = -(b + sq) / (2.0 * a);
+    t1 = -(b - sq) / (2.0 * a);
+}
+__device__ __forceinline__ void quad_roots(float a, float hb, float c, float disc4, float &t0, float &t1) {
+    float sq = sqrtf(disc4);
+    float q = -(hb + copysignf(sq, hb));
+    t0 = q / a;
+    t1 = (q != 0.0f) ? c / q : t0;
+}
+
+template <typename R>
+__device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> *tris, V3<R> o, V3<R> d, R t[4], R &u_out, R &v_out) {
+    const R EPS = (R)RTMI_EPSILON;
+    const R INF = Lim<R>::inf();
+    uint32_t kind = g.kind & LEAF_KIND_MASK;
+    int n = 0;
+    if (kind == RTMI_SPHERE) { // sphere.rs:47-63
+        R a = dot(d, d), hb = dot(d, o);
+        R disc4, c = dot(o, o) - (R)1;
+        if constexpr (sizeof(R) == 4) {
+            // |o - (hb/a) d|^2 avoids the b^2 - 4ac cancellation for distant origins
+            V3<R> l = o - d * (hb / a);
+            disc4 = a * ((R)1 - dot(l, l));
+        } else {
+            disc4 = hb * hb - a * c;
+        }
+        if (!(disc4 < (R)0)) {
+            quad_roots(a, hb, c, disc4, t[0], t[1]);
+            cswap(t[0], t[1]);
+            n = 2;
+        }
+    } else if (kind == RTMI_PLANE) { // plane.rs:35-44
+        if (!(abs_(d.y) < EPS)) { t[0] = -o.y / d.y; n = 1; }
+    } else if (kind == RTMI_CUBE) { // cube.rs:33-46,74-85
+        bool ok = true;
+        R tmin = -INF, tmax = INF;
+        R oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            if (dd[ax] == (R)0 && (oo[ax] < (R)-1 || oo[ax] > (R)1)) ok = false;
+            R a0 = ((R)-1 - oo[ax]) / dd[ax], a1 = ((R)1 - oo[ax]) / dd[ax];
+            R lo = a0 > a1 ? a1 : a0, hi = a0 > a1 ? a0 : a1;
+            tmin = ax == 0 ? lo : max_(tmin, lo);
+            tmax = ax == 0 ? hi : min_(tmax, hi);
+        }
+        if (ok && tmin <= tmax) { t[0] = tmin; t[1] = tmax; n = 2; }
+    } else if (kind == RTMI_CYLINDER || kind == RTMI_CONE) { // cylinder.rs:36-109, cone.rs:36-120
+        const bool cone = kind == RTMI_CONE;
+        R a = d.x * d.x + d.z * d.z, hb = o.x * d.x + o.z * d.z, c = o.x * o.x + o.z * o.z;
+        if (cone) { a -= d.y * d.y; hb -= o.y * d.y; c -= o.y * o.y; } else { c -= (R)1; }
+        R w0 = INF, w1 = INF, k0 = INF, k1 = INF; // wall roots, cap roots; +inf = absent
+        bool caps = true;
+        if (abs_(a) < EPS) {
+            // cone only: one root when b != 0 (cone.rs:88-97); the reference's b is 2*hb
+            if (cone && !(abs_((R)2 * hb) < EPS)) { w0 = c / ((R)-2 * ((R)2 * hb)); ++n; }
+        } else {
+            R disc4 = hb * hb - a * c;
+            if (disc4 < (R)0) {
+                caps = false; // cylinder.rs:89-90: no wall roots -> caps are skipped too
+            } else {
+                R t0, t1;
+                quad_roots(a, hb, c, disc4, t0, t1);
+                R y0 = o.y + t0 * d.y;
+                if (y0 > g.minimum && y0 < g.maximum) { w0 = t0; ++n; }
+                R y1 = o.y + t1 * d.y;
+                if (y1 > g.minimum && y1 < g.maximum) { w1 = t1; ++n; }
+            }
+        }
+        if (caps && (g.kind & LEAF_CLOSED) && abs_(d.y) > EPS) { // intersect_caps
+            R tc0 = (g.minimum - o.y) / d.y, tc1 = (g.maximum - o.y) / d.y;
+            R r0 = cone ? g.minimum * g.minimum : (R)1, r1 = cone ? g.maximum * g.maximum : (R)1;
+            R x0 = o.x + tc0 * d.x, z0 = o.z + tc0 * d.z;
+            if (x0 * x0 + z0 * z0 <= r0) { k0 = tc0; ++n; }
+            R x1 = o.x + tc1 * d.x, z1 = o.z + tc1 * d.z;
+            if (x1 * x1 + z1 * z1 <= r1) { k1 = tc1; ++n; }
+        }
+        // ascending; absent slots (+inf) sink to the end
+        t[0] = w0; t[1] = w1; t[2] = k0; t[3] = k1;
+        cswap(t[0], t[1]); cswap(t[2], t[3]); cswap(t[0], t[2]); cswap(t[1], t[3]); cswap(t[1], t[2]);
+    } else { // triangle.rs:233-265
+        const DTri<R> &tr = tris[g.tri];
+        V3<R> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+        V3<R> dir_cross_e2 = cross(d, e2);
+        R det = dot(e1, dir_cross_e2);
+        if (!(abs_(det) < EPS)) {
+            R f = (R)1 / det;
+            V3<R> p1_to_origin = o - ld3(tr.p1);
+            R u = f * dot(p1_to_origin, dir_cross_e2);
+            if (!(u < (R)0 || u > (R)1)) {
+                V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
+                R v = f * dot(d, origin_cross_e1);
+                if (!(v < (R)0 || (u + v) > (R)1)) {
+                    t[0] = f * dot(e2, origin_cross_e1);
+                    u_out = u; v_out = v;
+                    n = 1;
+                }
+            }
+        }
+    }
+    return n;
+}
+
+// Geometry::normal_at per kind (object space)
+template <typename R>
+__device__ __forceinline__ V3<R> local_normal(const DLeaf<R> &g, const DTri<R> *tris, V3<R> p, R u, R v) {
+    const R EPS = (R)RTMI_EPSILON;
+    uint32_t kind = g.kind & LEAF_KIND_MASK;
+    if (kind == RTMI_SPHERE) return p;               // sphere.rs:65-67
+    if (kind == RTMI_PLANE) return mk<R>(0, 1, 0);   // plane.rs:46-48
+    if (kind == RTMI_CUBE) {                         // cube.rs:48-67
+        R ax = abs_(p.x), ay = abs_(p.y), az = abs_(p.z);
+        if (ax >= ay) return ax >= az ? mk<R>(p.x, 0, 0) : mk<R>(0, 0, p.z);
+        return ay >= az ? mk<R>(0, p.y, 0) : mk<R>(0, 0, p.z);
+    }
+    if (kind == RTMI_CYLINDER || kind == RTMI_CONE) { // cylinder.rs:111-123, cone.rs:122-142
+        R dist = p.x * p.x + p.z * p.z;
+        if (dist < (R)1) {
+            if (p.y >= g.maximum - EPS) return mk<R>(0, 1, 0);
+            if (p.y <= g.minimum + EPS) return mk<R>(0, -1, 0);
+        }
+        if (kind == RTMI_CYLINDER) return mk<R>(p.x, 0, p.z);
+        R s = sqrt_(dist);
+        return mk<R>(p.x, p.y < (R)0 ? s : -s, p.z);
+    }
+    const DTri<R> &tr = tris[g.tri]; // triangle.rs:69-71,141-143
+    return normalize(ld3(tr.n2) * u + ld3(tr.n3) * v + ld3(tr.n1) * ((R)1 - u - v));
+}
+
+// World-space intersection of one leaf: Shape::intersect (shapes/mod.rs:252-255).  When the ray was
+// spawned on this very leaf, its root nearest to zero IS the spawn point (|t| ~ 1e-5): force it behind.
+template <typename R>
+__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, R t[4], R &u, R &v) {
+    V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
+    int n = local_intersect(g, tris, o, d, t, u, v);
+    if (is_origin && n > 0) {
+        int k = 0;
+        R best = abs_(t[0]);
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < n && abs_(t[i]) < best) { best = abs_(t[i]); k = i; }
+        R forced = -max_(best, (R)1e-30);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i == k) t[i] = forced;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Aabb::intersect (aabb.rs:45-70,130-141) on a conservatively padded f32 box
+// ---------------------------------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ bool slab(const DNode &nd, const Ray<R> &ray, R t_lo, R t_hi) {
+    R o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    R tmin = -Lim<R>::inf(), tmax = Lim<R>::inf();
+    bool ok = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        R lo = (R)nd.bmin[ax], hi = (R)nd.bmax[ax];
+        if (d[ax] == (R)0 && (o[ax] < lo || o[ax] > hi)) ok = false;
+        R a0 = (lo - o[ax]) / d[ax], a1 = (hi - o[ax]) / d[ax];
+        tmin = max_(tmin, min_(a0, a1));
+        tmax = min_(tmax, max_(a0, a1));
+    }
+    return ok && tmin <= tmax && tmin <= t_hi && tmax >= t_lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSG: CsgOp::eval (csg.rs:26-32)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool csg_eval(uint32_t op, bool lhit, bool inl, bool inr) {
+    if (op == RTMI_NODE_CSG_UNION) return (lhit && !inr) || (!lhit && !inl);
+    if (op == RTMI_NODE_CSG_INTERSECTION) return (lhit && inr) || (!lhit && inl);
+    return (lhit && !inr) || (!lhit && inl);
+}
+
+enum { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_COLLECT = 2 };
+
+// id word of a buffered CSG intersection
+constexpr uint32_t ID_LEAF_MASK = 0x0FFFFFFFu;
+constexpr uint32_t ID_ORD_SHIFT = 28;
+constexpr uint32_t ID_DONE = 1u << 31;
+constexpr uint32_t ID_KEEP = 1u << 30;
+
+template <typename R> struct Hit {
+    R t;
+    uint32_t leaf; // NONE = miss
+    uint32_t ord;  // which of the leaf's ascending roots
+};
+
+// result of the n1/n2 search
+template <typename R> struct Open {
+    R best_t, other_t;         // latest entry t among open leaves / among open leaves other than the hit leaf
+    uint32_t best, other;      // their leaves (NONE if none)
+    uint32_t hit_parity;       // number of hit-leaf roots in front of the hit (odd = hit leaf is open)
+};
+
+template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op, uint32_t leaf, uint32_t hit_leaf, R t_entry) {
+    if (op.best == NONE || t_entry > op.best_t) { op.best = leaf; op.best_t = t_entry; }
+    if (leaf != hit_leaf && (op.other == NONE || t_entry > op.other_t)) { op.other = leaf; op.other_t = t_entry; }
+}
+
+// Evaluate one CSG root (CsgPair::intersect + filter_intersections, csg.rs:97-124, recursively):
+// buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
+// its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
+template <typename R, int MODE>
+__device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray, uint32_t origin_leaf, Hit<R> &best, R t_limit,
+                         uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+    R bt[CSG_BUF];
+    uint32_t bid[CSG_BUF];
+    int k = 0;
+    for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li) {
+        const DLeaf<R> &g = sc.leaves[li];
+        if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) continue;
+        R t[4], u, v;
+        st.c[RTMI_STAT_LEAF_TESTS]++;
+        int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) {
+                if (k < CSG_BUF) { bt[k] = t[i]; bid[k] = li | ((uint32_t)i << ID_ORD_SHIFT); ++k; }
+                else st.c[RTMI_STAT_OVERFLOW] = 1;
+            }
+        }
+    }
+    unsigned long long state = 0; // bit 2b = inl, 2b+1 = inr of CSG operator b under this root
+    for (int step = 0; step < k; ++step) {
+        int m = -1;
+        R mt = Lim<R>::inf();
+        for (int i = 0; i < k; ++i)
+            if (!(bid[i] & ID_DONE) && (m < 0 || bt[i] < mt)) { m = i; mt = bt[i]; }
+        uint32_t id = bid[m];
+        uint32_t li = id & ID_LEAF_MASK;
+        bool keep = true;
+        for (uint32_t c = sc.leaves[li].csg_parent; c != NONE;) {
+            DCsg cn = sc.csgs[c];
+            bool lhit = li < cn.left_end;
+            bool inl = (state >> (2 * cn.bit)) & 1ull, inr = (state >> (2 * cn.bit + 1)) & 1ull;
+            bool filt = csg_eval(cn.op, lhit, inl, inr);
+            state ^= 1ull << (2 * cn.bit + (lhit ? 0 : 1));
+            if (!filt) { keep = false; break; }
+            c = cn.parent;
+        }
+        bid[m] = id | ID_DONE | (keep ? ID_KEEP : 0u);
+        if (MODE == MODE_COLLECT) continue;
+        if (keep && mt >= (R)0) {
+            if (mt < t_limit && mt < best.t) { best.t = mt; best.leaf = li; best.ord = (id >> ID_ORD_SHIFT) & 3u; }
+            return; // sorted: nothing later can be closer
+        }
+    }
+    if (MODE == MODE_COLLECT) {
+        // survivors in front of the hit, per leaf: odd count = still open, entered at its last such root
+        for (int i = 0; i < k; ++i) {
+            uint32_t id = bid[i];
+            if (!(id & ID_KEEP)) continue;
+            uint32_t li = id & ID_LEAF_MASK, ord = (id >> ID_ORD_SHIFT) & 3u;
+            bool front = (li == hit_leaf) ? (ord < hit_ord) : (bt[i] < t_limit);
+            if (!front) continue;
+            int cnt = 0;
+            bool last = true;
+            for (int j = 0; j < k; ++j) {
+                uint32_t jd = bid[j];
+                if (!(jd & ID_KEEP) || (jd & ID_LEAF_MASK) != li) continue;
+                uint32_t jo = (jd >> ID_ORD_SHIFT) & 3u;
+                bool jfront = (li == hit_leaf) ? (jo < hit_ord) : (bt[j] < t_limit);
+                if (!jfront) continue;
+                ++cnt;
+                if (jo > ord) last = false;
+            }
+            if (!last) continue;
+            if (li == hit_leaf) open.hit_parity = (uint32_t)cnt;
+            if (cnt & 1) open_candidate(open, li, hit_leaf, bt[i]);
+        }
+    }
+}
+
+// One leaf that is not under any CSG operator.
+template <typename R, int MODE>
+__device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, const DLeaf<R> &g, const Ray<R> &ray, uint32_t origin_leaf,
+                                           Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+    if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) return;
+    R t[4], u = 0, v = 0;
+    st.c[RTMI_STAT_LEAF_TESTS]++;
+    int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v);
+    if (MODE == MODE_COLLECT) {
+        int cnt = 0;
+        R last_t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bool front = i < n && ((li == hit_leaf) ? ((uint32_t)i < hit_ord) : (t[i] < t_limit));
+            if (front) { ++cnt; last_t = t[i]; }
+        }
+        if (li == hit_leaf) open.hit_parity = (uint32_t)cnt;
+        if (cnt & 1) open_candidate(open, li, hit_leaf, last_t);
+    } else {
+        // hit (ray.rs:143-154): the first root with t >= 0 of this leaf, kept if it beats the running minimum
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            if (i < n && t[i] >= (R)0 && t[i] < t_limit && t[i] < best.t) { best.t = t[i]; best.leaf = li; best.ord = (uint32_t)i; }
+        }
+    }
+}
+
+// World::intersect + hit (world.rs:145-156, ray.rs:143-154) / intersect_shadow + is_shadowed
+// (world.rs:158-180) / the container walk of ray.rs:111-140, as one traversal in three modes.
+//   MODE_CLOSEST: best = min t >= 0.            t_limit = +inf
+//   MODE_ANY    : best.leaf != NONE iff some shadow-casting root lies in [0, t_limit)
+//   MODE_COLLECT: open = which leaves the ray is inside of just in front of (t_limit, hit_leaf, hit_ord)
+template <typename R, int MODE>
+__device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, Hit<R> &best, R t_limit, uint32_t hit_leaf,
+                         uint32_t hit_ord, Open<R> &open, Stats &st) {
+    // top-level primitives: wave-uniform loop bounds -> leaf records come in through scalar loads
+    for (uint32_t li = 0; li < sc.root_leaf_count; ++li) {
+        plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+        if (MODE == MODE_ANY && best.leaf != NONE) return;
+    }
+    if (sc.root_child_count == 0) return;
+    uint32_t stack[NODE_STACK];
+    int sp = 0;
+    for (uint32_t c = sc.root_child_count; c-- > 0;) stack[sp++] = sc.root_child_first + c;
+    while (sp > 0) {
+        const DNode nd = sc.nodes[stack[--sp]];
+        if (MODE == MODE_ANY && !(nd.flags & NODE_CAST_SHADOW)) continue;
+        if (nd.flags & NODE_GATED) {
+            // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its
+            // negative-t roots for the in/out state); collect: anything in front of the hit counts
+            R hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
+            R lo = (MODE == MODE_COLLECT) ? -Lim<R>::inf() : (R)0;
+            if (!slab(nd, ray, lo, hi)) continue;
+        }
+        st.c[RTMI_STAT_NODE_VISITS]++;
+        if (nd.flags & NODE_CSGROOT) {
+            csg_root<R, MODE>(sc, nd, ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+        } else {
+            for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li)
+                plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+            for (uint32_t c = nd.child_count; c-- > 0;) {
+                if (sp < NODE_STACK) stack[sp++] = nd.child_first + c;
+                else st.c[RTMI_STAT_OVERFLOW] = 1;
+            }
+        }
+        if (MODE == MODE_ANY && best.leaf != NONE) return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// patterns (pattern.rs:7-35).  Rust's `%` keeps the sign of the dividend, so "x % 2 == 0" is
+// "x is an even integer" for integral x of either sign.
+// ---------------------------------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ bool is_even(R x) { R h = x * (R)0.5; return floor_(h) == h; }
+
+template <typename R> __device__ __forceinline__ V3<R> pattern_at(const DPattern<R> &p, V3<R> obj_point) {
+    const R EPS = (R)RTMI_EPSILON;
+    V3<R> q = xf_point(p.inv, obj_point); // pattern.rs:51-53
+    V3<R> a = ld3(p.a), b = ld3(p.b);
+    switch (p.kind) {
+    case RTMI_PATTERN_STRIPE: return is_even(floor_(q.x)) ? a : b;
+    case RTMI_PATTERN_GRADIENT: return a + (b - a) * (q.x - floor_(q.x));
+    case RTMI_PATTERN_RING: return is_even(floor_(sqrt_(q.x * q.x + q.z * q.z))) ? a : b;
+    case RTMI_PATTERN_CHECKERS: return is_even(floor_(q.x + EPS) + floor_(q.y + EPS) + floor_(q.z + EPS)) ? a : b;
+    default: return q; // RTMI_PATTERN_XYZ
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lights (lights.rs)
+// ---------------------------------------------------------------------------------------------
+enum { IL_RAY = 0, IL_OMNI = 1, IL_NOLIGHT = 2 };
+template <typename R> struct Incoming { int kind; V3<R> origin, direction, color; };
+
+__device__ __forceinline__ void sincos2pi(float u, float &s, float &c) { sincospif(2.0f * u, &s, &c); }
+__device__ __forceinline__ void sincos2pi(double u, double &s, double &c) { sincospi(2.0 * u, &s, &c); }
+__device__ __forceinline__ float exp_(float x) { return expf(x); }
+__device__ __forceinline__ double exp_(double x) { return exp(x); }
+// x in (0, 1], y = shininess: materials.rs:281 `powf`
+__device__ __forceinline__ float pow_(float x, float y) { return __builtin_exp2f(y * __builtin_log2f(x)); }
+__device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
+
+template <typename R> __device__ __forceinline__ Incoming<R> incoming_at(const DLight<R> &l, V3<R> p, Rng &rng) {
+    const R FOUR_PI = (R)(4.0 * 3.14159265358979323846);
+    Incoming<R> in;
+    V3<R> pos = ld3(l.pos);
+    in.kind = IL_RAY; in.origin = pos; in.color = ld3(l.intensity); in.direction = mk<R>(0, 0, 0);
+    switch (l.kind) {
+    case RTMI_LIGHT_POINT: // lights.rs:89-95
+        in.direction = normalize(pos - p);
+        break;
+    case RTMI_LIGHT_AMBIENT: // lights.rs:292-294
+        in.kind = IL_OMNI;
+        break;
+    case RTMI_LIGHT_REALISTIC_POINT: { // lights.rs:153-160
+        V3<R> d = pos - p;
+        in.direction = normalize(d);
+        in.color = in.color * ((R)1 / (FOUR_PI * dot(d, d)));
+        break;
+    }
+    case RTMI_LIGHT_BEAM: { // lights.rs:230-243
+        V3<R> dir = ld3(l.dir), up = ld3(l.up), right = ld3(l.right);
+        V3<R> d = p - pos;
+        if (dot(d, dir) < (R)0) { in.kind = IL_NOLIGHT; break; }
+        R u = dot(d, up) * l.inv_up2, v = dot(d, right) * l.inv_right2;
+        in.origin = pos + up * u + right * v;
+        in.direction = -dir;
+        in.color = in.color * exp_(-(u * u + v * v));
+        break;
+    }
+    case RTMI_LIGHT_SPHERE: { // lights.rs:353-362; UnitSphere by inverse CDF (two draws)
+        R u1 = rng_next<R>(rng), u2 = rng_next<R>(rng);
+        R z = (R)1 - (R)2 * u1, s, c;
+        sincos2pi(u2, s, c);
+        R rr = sqrt_(max_((R)0, (R)1 - z * z));
+        in.origin = pos + mk<R>(rr * c, rr * s, z) * l.radius;
+        in.direction = normalize(in.origin - p);
+        break;
+    }
+    case RTMI_LIGHT_DISC: { // lights.rs:438-453; UnitDisc by inverse CDF (two draws)
+        R u1 = rng_next<R>(rng), u2 = rng_next<R>(rng);
+        R rr = sqrt_(u1), s, c;
+        sincos2pi(u2, s, c);
+        in.origin = pos + ld3(l.width) * (rr * c) + ld3(l.height) * (rr * s);
+        V3<R> d = in.origin - p;
+        in.direction = normalize(d);
+        R cosn = max_(dot(-in.direction, ld3(l.normal)), (R)0);
+        in.color = (in.color * cosn) * ((R)1 / (FOUR_PI * dot(d, d)));
+        break;
+    }
+    default: in.kind = IL_NOLIGHT;
+    }
+    return in;
+}
+
+// Phong::lighting (materials.rs:246-288)
+template <typename R>
+__device__ __forceinline__ V3<R> lighting(const DMaterial<R> &m, V3<R> surface_color, const Incoming<R> &light, V3<R> eyev, V3<R> normalv,
+                                          bool in_shadow) {
+    if (light.kind == IL_NOLIGHT) return mk<R>(0, 0, 0);
+    if (light.kind == IL_OMNI) return had(surface_color, light.color);
+    if (in_shadow) return mk<R>(0, 0, 0);
+    R light_dot_normal = dot(light.direction, normalv);
+    if (light_dot_normal <= (R)0) return mk<R>(0, 0, 0);
+    V3<R> result = had(surface_color, light.color) * (m.diffuse * light_dot_normal);
+    V3<R> ml = -light.direction;
+    V3<R> reflectv = ml - normalv * ((R)2 * dot(ml, normalv));
+    R reflect_dot_eye = dot(reflectv, eyev);
+    if (reflect_dot_eye > (R)0) result = result + light.color * (m.specular * pow_(reflect_dot_eye, m.shininess));
+    return result;
+}
+
+// schlick (ray.rs:199-219)
+template <typename R> __device__ __forceinline__ R schlick(V3<R> eyev, V3<R> normalv, R n1, R n2) {
+    R cos_en = dot(eyev, normalv);
+    if (n1 > n2) {
+        R n = n1 / n2;
+        R sin2_t = n * n * ((R)1 - cos_en * cos_en);
+        if (sin2_t > (R)1) return (R)1;
+        cos_en = sqrt_((R)1 - sin2_t);
+    }
+    R r0 = (n1 - n2) / (n1 + n2);
+    r0 = r0 * r0;
+    R tmp = (R)1 - cos_en, tmp2 = tmp * tmp;
+    return r0 + ((R)1 - r0) * (tmp2 * tmp2 * tmp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// prepare_computations (ray.rs:72-102) for the closest hit
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct Comps {
+    V3<R> point, eyev, normalv;
+    bool inside;
+    R n1, n2;
+};
+
+template <typename R>
+__device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, const Hit<R> &h, Comps<R> &c) {
+    const DLeaf<R> &g = sc.leaves[h.leaf];
+    c.point = ray.o + ray.d * h.t; // Ray::position, ray.rs:26-28
+    c.eyev = -ray.d;
+    V3<R> obj_point = xf_point(g.inv, c.point);
+    R u = 0, v = 0;
+    if ((g.kind & LEAF_KIND_MASK) >= RTMI_TRIANGLE) { // barycentrics of the hit (triangle.rs:250,257)
+        const DTri<R> &tr = sc.tris[g.tri];
+        V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d);
+        V3<R> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+        V3<R> dir_cross_e2 = cross(d, e2);
+        R f = (R)1 / dot(e1, dir_cross_e2);
+        V3<R> p1_to_origin = o - ld3(tr.p1);
+        u = f * dot(p1_to_origin, dir_cross_e2);
+        v = f * dot(d, cross(p1_to_origin, e1));
+    }
+    V3<R> n = normalize(xf_normal(g.inv, local_normal(g, sc.tris, obj_point, u, v))); // shapes/mod.rs:261-265,319-322
+    c.inside = dot(n, c.eyev) < (R)0;
+    c.normalv = c.inside ? -n : n;
+    c.n1 = (R)1; c.n2 = (R)1;
+}
+
+// compute_refractive_indices (ray.rs:104-140) without the sorted list: a leaf is "open" in front of
+// the hit iff an odd number of its intersections precede the hit, and containers.last() is the open
+// leaf that was entered last (largest entry t).
+template <typename R>
+__device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, const Hit<R> &h, Comps<R> &c,
+                                             Stats &st) {
+    Open<R> open;
+    open.best = NONE; open.other = NONE; open.best_t = 0; open.other_t = 0; open.hit_parity = 0;
+    Hit<R> dummy = {Lim<R>::inf(), NONE, 0};
+    traverse<R, MODE_COLLECT>(sc, ray, origin_leaf, dummy, h.t, h.leaf, h.ord, open, st);
+    c.n1 = open.best != NONE ? sc.materials[sc.leaves[open.best].material].ior : (R)1;
+    if (open.hit_parity & 1u) c.n2 = open.other != NONE ? sc.materials[sc.leaves[open.other].material].ior : (R)1;
+    else c.n2 = sc.materials[sc.leaves[h.leaf].material].ior;
+}
+
+template <typename R> struct Pending { // a refraction ray waiting for its turn (materials.rs:327-331)
+    V3<R> o, d;
+    R weight;
+    int32_t remaining;
+    uint32_t origin_leaf;
+};
+
+// World::is_shadowed (world.rs:172-180)
+template <typename R>
+__device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<R> &in, V3<R> p, uint32_t origin_leaf, Stats &st) {
+    if (in.kind == IL_OMNI) return false;
+    if (in.kind == IL_NOLIGHT) return true;
+    st.c[RTMI_STAT_SHADOW]++;
+    Ray<R> sray = {p, in.direction};
+    V3<R> to_light = in.origin - p;
+    R dist = sqrt_(dot(to_light, to_light));
+    Hit<R> sh = {Lim<R>::inf(), NONE, 0};
+    Open<R> unused;
+    traverse<R, MODE_ANY>(sc, sray, origin_leaf, sh, dist, NONE, 0, unused, st);
+    return sh.leaf != NONE;
+}
+
+// World::color_at (world.rs:115-118) with Phong::shade_hit (materials.rs:371-412) unrolled into a loop:
+// shade_hit is linear in its children's colours, so each ray carries the product of the factors
+// above it ("weight") and adds weight * (clipped direct light + emissive) to the sample.
+template <typename R>
+__device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
+    const R EPS = (R)RTMI_EPSILON;
+    V3<R> acc = mk<R>(0, 0, 0);
+    R weight = (R)1;
+    uint32_t origin_leaf = NONE;
+    int cls = RTMI_STAT_PRIMARY;
+    Pending<R> stack[MAX_DEPTH];
+    int sp = 0;
+    bool first = true;
+    for (;;) {
+        if (cls == RTMI_STAT_PRIMARY) st.c[RTMI_STAT_PRIMARY]++;
+        else if (cls == RTMI_STAT_REFLECTION) st.c[RTMI_STAT_REFLECTION]++;
+        else st.c[RTMI_STAT_REFRACTION]++;
+        Hit<R> h = {Lim<R>::inf(), NONE, 0};
+        Open<R> unused;
+        traverse<R, MODE_CLOSEST>(sc, ray, origin_leaf, h, Lim<R>::inf(), NONE, 0, unused, st);
+        bool spawned = false;
+        if (h.leaf != NONE) {
+            Comps<R> c;
+            prepare(sc, ray, h, c);
+            const DLeaf<R> &g = sc.leaves[h.leaf];
+            const DMaterial<R> m = sc.materials[g.material];
+            V3<R> over_point = c.point + c.normalv * EPS;
+            // Phong::color_at (materials.rs:239-244): patterns are looked up at comps.point
+            V3<R> surface_color = ld3(m.color);
+            if (m.pattern >= 0) surface_color = pattern_at(sc.patterns[m.pattern], xf_point(g.inv, c.point));
+            V3<R> surface = mk<R>(0, 0, 0);
+            for (uint32_t li = 0; li < sc.n_lights; ++li) { // materials.rs:386-397
+                Incoming<R> in = incoming_at(sc.lights[li], over_point, rng);
+                bool in_shadow = is_shadowed(sc, in, over_point, h.leaf, st);
+                surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
+            }
+            surface = mk<R>(min_(max_(surface.x, (R)0), (R)1), min_(max_(surface.y, (R)0), (R)1), min_(max_(surface.z, (R)0), (R)1)); // :399
+            acc = acc + (surface + surface_color * m.emissive) * weight;
+
+            bool want_n = first_comps && first;
+            bool do_refl = !(m.reflective == (R)0) && remaining > 0;   // materials.rs:297
+            bool do_refr = !(m.transparency == (R)0) && remaining > 0; // materials.rs:316
+            if (do_refr || want_n) collect_n1n2(sc, ray, origin_leaf, h, c, st);
+            if (first) {
+                if (first_hit) *first_hit = h;
+                if (first_comps) *first_comps = c;
+            }
+            R w_refl = weight * m.reflective, w_refr = weight * m.transparency;
+            if (m.reflective > (R)0 && m.transparency > (R)0 && remaining > 0) { // materials.rs:406-408
+                R reflectance = schlick(c.eyev, c.normalv, c.n1, c.n2);
+                w_refl *= reflectance;
+                w_refr *= (R)1 - reflectance;
+            }
+            Ray<R> refr_ray = ray;
+            if (do_refr) { // materials.rs:319-326
+                R n_ratio = c.n1 / c.n2;
+                R cos_i = dot(c.eyev, c.normalv);
+                R sin2_t = n_ratio * n_ratio * ((R)1 - cos_i * cos_i);
+                if (sin2_t > (R)1) {
+                    do_refr = false;
+                } else {
+                    R cos_t = sqrt_((R)1 - sin2_t);
+                    refr_ray.o = c.point - c.normalv * EPS;
+                    refr_ray.d = c.normalv * (n_ratio * cos_i - cos_t) - c.eyev * n_ratio;
+                }
+            }
+            if (do_refl) {
+                if (do_refr && sp < MAX_DEPTH) {
+                    stack[sp].o = refr_ray.o; stack[sp].d = refr_ray.d; stack[sp].weight = w_refr;
+                    stack[sp].remaining = remaining - 1; stack[sp].origin_leaf = h.leaf;
+                    ++sp;
+                }
+                ray.d = ray.d - c.normalv * ((R)2 * dot(ray.d, c.normalv)); // reflectv, ray.rs:84
+                ray.o = over_point;
+                weight = w_refl; remaining -= 1; origin_leaf = h.leaf; cls = RTMI_STAT_REFLECTION;
+                spawned = true;
+            } else if (do_refr) {
+                ray = refr_ray;
+                weight = w_refr; remaining -= 1; origin_leaf = h.leaf; cls = RTMI_STAT_REFRACTION;
+                spawned = true;
+            }
+        } else if (first && first_hit) {
+            *first_hit = h;
+        }
+        first = false;
+        if (!spawned) {
+            if (sp == 0) break;
+            --sp;
+            ray.o = stack[sp].o; ray.d = stack[sp].d; weight = stack[sp].weight;
+            remaining = stack[sp].remaining; origin_leaf = stack[sp].origin_leaf; cls = RTMI_STAT_REFRACTION;
+        }
+    }
+    return acc;
+}
+
+// Camera::ray_for_pixel (camera.rs:120-153)
+template <typename R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera<R> &cam, int px, int py, bool randomize, Rng &rng) {
+    R jx = (R)0.5, jy = (R)0.5;
+    if (randomize) { jx = rng_next<R>(rng); jy = rng_next<R>(rng); }
+    R x_offset = ((R)px + jx) * cam.pixel_size;
+    R y_offset = ((R)py + jy) * cam.pixel_size;
+    R world_x = cam.half_width - x_offset, world_y = cam.half_height - y_offset;
+    V3<R> pixel = xf_point(cam.inv, mk<R>(world_x, world_y, (R)-1));
+    V3<R> origin = mk<R>(cam.inv[3], cam.inv[7], cam.inv[11]);
+    Ray<R> r = {origin, normalize(pixel - origin)};
+    if (cam.aperture_size == (R)0) return r;
+    V3<R> focal_point = r.o + r.d * cam.focal_distance;
+    R a0 = rng_next<R>(rng), a1 = rng_next<R>(rng);
+    V3<R> ap_pixel = pixel + mk<R>((a0 - (R)0.5) * cam.aperture_size, (a1 - (R)0.5) * cam.aperture_size, (R)0);
+    Ray<R> s = {ap_pixel, normalize(focal_point - ap_pixel)};
+    return s;
+}
+
+} // namespace rtmi_dev

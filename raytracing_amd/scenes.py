@@ -1,0 +1,381 @@
+"""The BASELINE scenes, restated with the front end (same builder calls as the reference's example programs),
+and the Scheme twin's deterministic scenes used as golden images.
+
+Each function returns (World, Camera).  Citations: rust/examples/*.rs and scheme/chapterNN.scm of the reference.
+Cameras take (hsize, vsize); samplers are set as the cited example ships them unless `deterministic=True`
+(min_samples 1, standard error 1.0 -> exactly one centred ray per pixel, camera.rs:378-389).
+"""
+import math
+import os
+
+from . import _front as rt
+
+PI = math.pi
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+def _camera(h, v, frm, to, se=None, min_samples=None, deterministic=False, fov=PI / 3.0):
+    cam = rt.Camera(h, v, fov).with_view_transform(rt.point(*frm), rt.point(*to), rt.vector(0, 1, 0))
+    if deterministic:
+        cam.set_min_samples(1)
+        cam.set_allowed_standard_error(1.0)
+    else:
+        if se is not None:
+            cam.set_allowed_standard_error(se)
+        if min_samples is not None:
+            cam.set_min_samples(min_samples)
+    return cam
+
+
+# ------------------------------------------------------------------------------------------------
+# Rust examples (BASELINE configs 1-5)
+# ------------------------------------------------------------------------------------------------
+def chapter07(h=900, v=450, deterministic=False):
+    """rust/examples/chapter-07.rs:13-83 — BASELINE config 1."""
+    w = rt.World.empty()
+    w.add_light(rt.AmbientLight(rt.color(0.1, 0.1, 0.1)))
+    w.add_light(rt.PointLight(rt.point(-10, 10, -10), rt.color(1, 1, 1)))
+    floor_material = rt.Phong.default().with_color(rt.color(1, 0.9, 0.9)).with_specular(0.0).with_shininess(100.0)
+    w.add_item(rt.sphere().with_transform(rt.scaling(10, 0.01, 10)).with_material(floor_material))
+    w.add_item(rt.sphere().with_transform(
+        rt.translation(0, 0, 5) * rt.rotation_y(-PI / 4.0) * rt.rotation_x(-PI / 2.0) * rt.scaling(10, 0.01, 10)).with_material(floor_material))
+    w.add_item(rt.sphere().with_transform(
+        rt.translation(0, 0, 5) * rt.rotation_y(PI / 4.0) * rt.rotation_x(PI / 2.0) * rt.scaling(10, 0.01, 10)).with_material(floor_material))
+    w.add_item(rt.sphere().with_transform(rt.translation(-0.5, 1, 0.5)).with_material(
+        rt.Phong.default().with_rgb(0.1, 1.0, 0.5).with_diffuse(0.7).with_specular(0.3)))
+    w.add_item(rt.sphere().with_transform(rt.translation(1.5, 0.5, -0.5) * rt.scaling(0.5, 0.5, 0.5)).with_material(
+        rt.Phong.default().with_rgb(0.5, 1.0, 0.1).with_diffuse(0.7).with_specular(0.3)))
+    w.add_item(rt.sphere().with_transform(rt.translation(-1.5, 0.33, -0.75) * rt.scaling(0.33, 0.33, 0.33)).with_material(
+        rt.Phong.default().with_rgb(1.0, 0.8, 0.1).with_diffuse(0.7).with_specular(0.3)))
+    return w, _camera(h, v, (0, 1.5, -5), (0, 1, 0), se=1e-2, deterministic=deterministic)
+
+
+def _sky():
+    return rt.plane().with_transform(rt.translation(0, 1000, 0)).with_material(
+        rt.Phong.default().with_color(rt.color(0.8, 0.8, 1)).with_emissive(1.0).with_diffuse(1.0).with_specular(0.0))
+
+
+def chapter11a(h=900, v=450, deterministic=False, max_depth=5):
+    """rust/examples/chapter-11a.rs:14-82 — BASELINE config 2 (depth 5; the Rust default is 10, world.rs:61)."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(max_depth)
+    w.add_light(rt.PointLight(rt.point(-10, 10, -10), rt.color(1, 1, 1)))
+    floor_material = rt.Phong.default().with_pattern(
+        rt.checkers_pattern(rt.color(0.75, 0.25, 0.5), rt.color(0.25, 0.75, 0.5))).with_diffuse(0.9).with_specular(0.0)
+    w.add_item(rt.plane().with_material(floor_material))
+    w.add_item(_sky())
+    w.add_item(rt.sphere().with_transform(rt.translation(-1.5, 1, 0.5)).with_material(
+        rt.Phong.default().with_color(rt.color(0, 0, 0)).with_diffuse(0.0).with_specular(0.8).with_reflective(1.0)))
+    w.add_item(rt.sphere().with_transform(rt.translation(1.5, 1, 0.5)).with_material(
+        rt.Phong.default().with_color(rt.color(0, 0, 0)).with_diffuse(0.0).with_specular(0.8).with_reflective(1.0)
+        .with_transparency(1.0).with_refractive_index(1.5)))
+    w.add_item(rt.sphere().with_transform(rt.translation(1.5, 1, 0.5) * rt.scaling(0.5, 0.5, 0.5)).with_material(
+        rt.Phong.default().with_color(rt.color(0, 0, 0)).with_diffuse(0.0).with_specular(0.8).with_reflective(1.0)
+        .with_transparency(1.0).with_refractive_index(1.0)))
+    return w, _camera(h, v, (0, 1.5, -5), (0, 1, 0), se=1e-2, deterministic=deterministic)
+
+
+def chapter11b(h=900, v=450, deterministic=False, max_depth=5):
+    """rust/examples/chapter-11b.rs:13-87 — BASELINE config 2, water variant."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(max_depth)
+    w.add_light(rt.PointLight(rt.point(-10, 10, -10), rt.color(1, 1, 1)))
+    floor_material = rt.Phong.default().with_pattern(
+        rt.checkers_pattern(rt.color(0.25, 0.25, 0.75), rt.color(0.25, 0.75, 0.25))).with_diffuse(0.9).with_specular(0.0)
+    w.add_item(rt.plane().with_material(floor_material).with_transform(rt.translation(0, -1, 0)))
+    water_material = (rt.Phong.default().with_color(rt.color(0.1, 0.1, 0.5)).with_diffuse(1.0).with_specular(0.5)
+                      .with_reflective(1.0).with_transparency(1.0).with_refractive_index(1.3))
+    w.add_item(rt.plane().with_cast_shadow(False).with_material(water_material).with_transform(rt.translation(0, 0, 0)))
+    w.add_item(_sky())
+    w.add_item(rt.sphere().with_transform(rt.translation(-1.5, 1, 5.5)).with_material(
+        rt.Phong.default().with_color(rt.color(1, 0, 0)).with_diffuse(0.5).with_specular(0.8)))
+    w.add_item(rt.sphere().with_transform(rt.translation(1.5, -0.25, 0.5)).with_material(
+        rt.Phong.default().with_color(rt.color(0, 1, 0)).with_diffuse(0.1).with_specular(0.8)))
+    return w, _camera(h, v, (0, 1.5, -5), (0, 1, 0), se=1e-2, deterministic=deterministic)
+
+
+def teapot_obj_text(lite=False):
+    path = os.path.join(_DATA, "teapot-lite.obj" if lite else "teapot.obj")
+    with open(path, "r") as f:
+        return f.read()
+
+
+def chapter15(h=900, v=450, deterministic=False, lite=False, depth_of_field=False, max_leaf=10):
+    """rust/examples/chapter-15.rs:15-57 — BASELINE config 3: teapot mesh, host-built BVH (leaf <= 10),
+    hard shadows.  The example also switches on depth of field; config 3 does not (`depth_of_field=False`)."""
+    w = rt.World.empty()
+    w.add_light(rt.AmbientLight(rt.color(0.25, 0.25, 0.25)))
+    w.add_light(rt.PointLight(rt.point(-10, 10, -10), rt.color(0.75, 0.75, 0.75)))
+    floor_material = rt.Phong.default().with_pattern(
+        rt.checkers_pattern(rt.color(0.25, 0.25, 0.75), rt.color(0.25, 0.75, 0.25))).with_diffuse(0.9).with_specular(0.0)
+    w.add_item(rt.plane().with_material(floor_material).with_transform(rt.translation(0, -1, 0)))
+    teapot = rt.ObjParser.parse_str(teapot_obj_text(lite)).into_group()
+    teapot = teapot.with_transform(rt.rotation_y(PI / 4.0) * rt.rotation_x(-PI / 2.0) * rt.scaling(0.2, 0.2, 0.2))
+    w.add_item(rt.build_bounding_tree(teapot, max_leaf))
+    w.finalize_scene()
+    frm, to = (0, 5, -8), (0, 1, 0)
+    cam = _camera(h, v, frm, to, se=1e-2, min_samples=10, deterministic=deterministic)
+    if depth_of_field:
+        cam.set_focal_distance(math.sqrt(sum((a - b) ** 2 for a, b in zip(to, frm))))
+        cam.set_aperture_size(0.1)
+    return w, cam
+
+
+def soft_shadow(h=900, v=450, deterministic=False):
+    """rust/examples/soft_shadow.rs:12-59 — BASELINE config 4 (area light)."""
+    w = rt.World.empty()
+    w.add_light(rt.SphereLight(rt.point(-5, 2, -5), 2.0, rt.color(1.5, 1.5, 1.5)))
+    w.add_item(rt.sphere().with_transform(rt.translation(-5, 2, -5) * rt.scaling(2, 2, 2)).with_material(
+        rt.Phong.default().with_rgb(1.0, 1.0, 1.0).with_emissive(1.0).with_diffuse(0.0).with_specular(0.0).with_reflective(0.0))
+        .with_cast_shadow(False))
+    floor_material = rt.Phong.default().with_color(rt.color(1.0, 1.0, 1.0)).with_diffuse(0.8).with_specular(0.0)
+    w.add_item(rt.plane().with_material(floor_material))
+    w.add_item(rt.cube().with_transform(rt.translation(0.0, 1, 0.0)).with_material(
+        rt.Phong.default().with_rgb(1.0, 1.0, 1.0).with_diffuse(0.8).with_specular(0.0).with_reflective(0.0)))
+    return w, _camera(h, v, (9, 15, -19), (1.5, 1, 1), se=1e-2, min_samples=10, deterministic=deterministic)
+
+
+def depth_of_field(h=900, v=450, deterministic=False):
+    """rust/examples/depth-of-field.rs:13-85 — BASELINE config 4 (thin lens)."""
+    w = rt.World.empty()
+    w.add_light(rt.PointLight(rt.point(-10, 10, -10), rt.color(0.5, 0.5, 0.5)))
+    w.add_light(rt.PointLight(rt.point(-10, 10, 10), rt.color(0.5, 0.5, 0.5)))
+    floor_material = rt.Phong.default().with_pattern(
+        rt.checkers_pattern(rt.color(0.1, 0.1, 0.1), rt.color(0.9, 0.9, 0.9))).with_specular(0.0)
+    w.add_item(rt.plane().with_material(floor_material))
+    w.add_item(_sky())
+    ball = rt.Phong.default().with_rgb(0.1, 1.0, 0.5).with_diffuse(0.7).with_specular(0.3)
+    w.add_item(rt.sphere().with_transform(rt.translation(-1.5, 1, 0.5)).with_material(ball))
+    w.add_item(rt.sphere().with_transform(rt.translation(0.5, 1, 10.5)).with_material(ball))
+    w.add_item(rt.sphere().with_transform(rt.translation(1.5, 1, -3.5)).with_material(
+        rt.Phong.default().with_rgb(0.5, 0.1, 1.0).with_diffuse(0.7).with_specular(0.3)))
+    w.add_item(rt.sphere().with_transform(rt.translation(2.0, 1, 4.5)).with_material(
+        rt.Phong.default().with_rgb(0.0, 0.0, 0.0).with_diffuse(0.0).with_specular(1.0).with_reflective(1.0)))
+    cam = _camera(h, v, (0, 1.5, -5), (0, 1, 0), se=5e-3, deterministic=deterministic)
+    cam.set_focal_distance(10.0)
+    cam.set_aperture_size(0.25)
+    return w, cam
+
+
+# --- chapter-16 dice (rust/examples/chapter-16.rs:17-107) ---
+def _dice_point(i, j, mat):
+    return rt.sphere().with_material(mat).with_transform(rt.translation(0.5 * i, 1, 0.5 * j) * rt.scaling(0.2, 0.1, 0.2))
+
+
+def _dice_side(points, mat):
+    if len(points) == 1:
+        return rt.SceneItem(_dice_point(points[0][0], points[0][1], mat))
+    g = rt.group()
+    for (i, j) in points:
+        g = g.with_child(_dice_point(i, j, mat))
+    return rt.SceneItem(g)
+
+
+_SIDES = {
+    1: [(0.0, 0.0)],
+    2: [(-0.8, -0.8), (0.8, 0.8)],
+    3: [(0.0, 0.0), (-1.0, -1.0), (1.0, 1.0)],
+    4: [(-0.8, -0.8), (-0.8, 0.8), (0.8, -0.8), (0.8, 0.8)],
+    5: [(0.0, 0.0), (-1.0, -1.0), (1.0, -1.0), (-1.0, 1.0), (1.0, 1.0)],
+    6: [(-1.0, -1.0), (-1.0, 0.0), (-1.0, 1.0), (1.0, -1.0), (1.0, 0.0), (1.0, 1.0)],
+}
+
+
+def dice(mat1, mat2):
+    body = rt.csg_intersection(rt.cube().with_material(mat1), rt.sphere().with_material(mat1).with_transform(rt.scaling(1.5, 1.5, 1.5)))
+    body = rt.csg_difference(body, _dice_side(_SIDES[1], mat2))
+    body = rt.csg_difference(body, _dice_side(_SIDES[6], mat2).with_transform(rt.scaling(1, -1, 1)))
+    body = rt.csg_difference(body, _dice_side(_SIDES[2], mat2).with_transform(rt.rotation_x(PI / 2.0)))
+    body = rt.csg_difference(body, _dice_side(_SIDES[5], mat2).with_transform(rt.rotation_x(-PI / 2.0)))
+    body = rt.csg_difference(body, _dice_side(_SIDES[3], mat2).with_transform(rt.rotation_z(PI / 2.0)))
+    body = rt.csg_difference(body, _dice_side(_SIDES[4], mat2).with_transform(rt.rotation_z(-PI / 2.0)))
+    return rt.SceneItem(body)
+
+
+def _philox_uniform(seed, index, k):
+    """Same stream as the renderers (oracle/rt_oracle.c orc_uniform): scene randomness of chapter-16 is keyed
+    by the die index so that the scene is reproducible (the reference uses thread_rng, chapter-16.rs:145-157)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [index & 0xFFFFFFFF, 0xD1CE, k >> 2, 0x52544D49]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return (c[k & 3] >> 8) / 16777216.0
+
+
+def chapter16(h=900, v=450, deterministic=False, seed=0x5EED, nx=8, ny=4, max_depth=10):
+    """rust/examples/chapter-16.rs:109-176 — BASELINE config 5: CSG dice (17 x 9) + lens, BVH leaf 2."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(max_depth)
+    w.add_light(rt.AmbientLight(rt.color(0.5, 0.5, 0.5)))
+    w.add_light(rt.PointLight(rt.point(-9, 8, -7), rt.color(1, 1, 1)))
+    floor_material = rt.Phong.default().with_pattern(
+        rt.checkers_pattern(rt.color(0.75, 0.75, 0.75), rt.color(0.9, 0.9, 0.9)).with_transform(rt.scaling(0.1, 0.1, 0.1))
+    ).with_diffuse(0.5).with_specular(0.0)
+    w.add_item(rt.plane().with_material(floor_material).with_transform(rt.translation(0, 0, 2) * rt.rotation_x(PI / 2.0)))
+    glass = rt.Phong.new(rt.color(0, 0, 0), 0.0, 0.0, 0.9, 500.0, 1.0, 1.0, 1.5)
+    a = rt.sphere().with_material(glass).with_transform(rt.translation(0, 0, 0.8))
+    b = rt.sphere().with_material(glass).with_transform(rt.translation(0, 0, -0.8))
+    w.add_item(rt.csg_intersection(a, b).with_transform(rt.translation(0.0, 0, 0)).with_cast_shadow(False))
+    dices = rt.group()
+    idx = 0
+    for i in range(-nx, nx + 1):
+        for j in range(-ny, ny + 1):
+            u = [_philox_uniform(seed, idx, k) for k in range(8)]
+            idx += 1
+            hue = u[0] * 360.0
+            mat1 = rt.Phong.default().with_hsv(hue, 0.8, 1.0).with_diffuse(1.0)
+            mat2 = rt.Phong.default().with_hsv(hue + 180.0, 0.8, 1.0).with_diffuse(1.0)
+            size = 0.05 + u[1] * 0.05
+            pos_x = i * 0.4 + (-0.1 + u[2] * 0.2)
+            pos_y = j * 0.4 + (-0.1 + u[3] * 0.2)
+            phi = u[4] * 2.0 * PI
+            rotax = rt.vector(u[5], u[6], u[7]).normalized()
+            dices.add_child(dice(mat1, mat2).with_transform(
+                rt.translation(pos_x, pos_y, 1.8) * rt.Matrix.identity().rotate(phi, rotax) * rt.scaling(size, size, size)))
+    w.add_item(rt.build_bounding_tree(dices, 2))
+    w.finalize_scene()
+    return w, _camera(h, v, (0, 0, -3), (0, 0, 0), se=1e-2, min_samples=10, deterministic=deterministic)
+
+
+# ------------------------------------------------------------------------------------------------
+# Scheme twin scenes (scheme/chapterNN.scm): 320x160, 1 centred ray per pixel, depth 5, white point light.
+# Scheme `ambient a` == Rust `emissive a` under a white light.
+# (material color ambient diffuse specular shininess [reflective transparency refractive-index])
+# ------------------------------------------------------------------------------------------------
+def _smat(col, ambient, diffuse, specular, shininess, reflective=0.0, transparency=0.0, ior=1.0, pattern=None):
+    m = rt.Phong.new(rt.color(*col) if col is not None else rt.color(0, 0, 0), ambient, diffuse, specular, shininess, reflective,
+                     transparency, ior)
+    return m.with_pattern(pattern) if pattern is not None else m
+
+
+def _scheme_world(items, light=(-10, 10, -10)):
+    w = rt.World.empty()
+    w.set_max_reflection_depth(5)  # MAX-BOUNCE-DEPTH, scheme/raytrace/world.sld:40
+    w.add_light(rt.PointLight(rt.point(*light), rt.color(1, 1, 1)))
+    for it in items:
+        w.add_item(it)
+    return w
+
+
+def _scheme_camera(frm=(0, 1.5, -5), to=(0, 1, 0)):
+    return _camera(320, 160, frm, to, deterministic=True)
+
+
+def _three_balls(kind, mats):
+    mk = {"sphere": rt.sphere, "cylinder": rt.cylinder}[kind]
+    return [
+        mk().with_transform(rt.translation(-0.5, 1, 0.5)).with_material(mats[0]),
+        mk().with_transform(rt.translation(1.5, 0.5, -0.5) * rt.scaling(0.5, 0.5, 0.5)).with_material(mats[1]),
+        mk().with_transform(rt.translation(-1.5, 0.33, -0.75) * rt.scaling(0.33, 0.33, 0.33)).with_material(mats[2]),
+    ]
+
+
+def scheme_chapter08(shadows=True):
+    """scheme/chapter08.scm (== chapter07.scm; chapter07.ppm predates shadows -> shadows=False)."""
+    fm = _smat((1, 0.9, 0.9), 0.1, 0.9, 0.0, 100.0)
+    walls = [
+        rt.sphere().with_transform(rt.scaling(10, 0.01, 10)).with_material(fm),
+        rt.sphere().with_transform(rt.translation(0, 0, 5) * rt.rotation_y(-PI / 4) * rt.rotation_x(-PI / 2) * rt.scaling(10, 0.01, 10)).with_material(fm),
+        rt.sphere().with_transform(rt.translation(0, 0, 5) * rt.rotation_y(PI / 4) * rt.rotation_x(PI / 2) * rt.scaling(10, 0.01, 10)).with_material(fm),
+    ]
+    balls = _three_balls("sphere", [_smat((0.1, 1, 0.5), 0.1, 0.7, 0.3, 200.0), _smat((0.5, 1, 0.1), 0.1, 0.7, 0.3, 200.0),
+                                    _smat((1, 0.8, 0.1), 0.1, 0.7, 0.3, 200.0)])
+    items = walls + balls
+    if not shadows:
+        items = [s.with_cast_shadow(False) for s in items]
+    return _scheme_world(items), _scheme_camera()
+
+
+def scheme_chapter09():
+    """scheme/chapter09.scm."""
+    floor = rt.plane().with_material(_smat((1, 0.9, 0.9), 0.1, 0.9, 0.0, 100.0))
+    balls = _three_balls("sphere", [_smat((0.1, 1, 0.5), 0.1, 0.7, 0.3, 200.0), _smat((0.5, 1, 0.1), 0.1, 0.7, 0.3, 200.0),
+                                    _smat((1, 0.8, 0.1), 0.1, 0.7, 0.3, 200.0)])
+    return _scheme_world([floor] + balls), _scheme_camera()
+
+
+def scheme_chapter10():
+    """scheme/chapter10.scm:16-37."""
+    c = rt.color
+    ground = rt.plane().with_material(_smat(None, 0.1, 0.9, 0.0, 100.0, pattern=rt.stripe_pattern(c(0.5, 0.5, 0.5), c(1, 0.9, 0.9))))
+    balls = _three_balls("sphere", [
+        _smat(None, 0.1, 0.7, 0.3, 200.0, pattern=rt.gradient_pattern(c(0.9, 0, 0.5), c(0.1, 1, 0.5))),
+        _smat(None, 0.1, 0.7, 0.3, 200.0, pattern=rt.stripe_pattern(c(0.5, 0.5, 0.5), c(0.5, 1, 0.1))),
+        _smat(None, 0.1, 0.7, 0.3, 200.0, pattern=rt.stripe_pattern(c(0.5, 0.5, 0.5), c(1, 0.8, 0.1))),
+    ])
+    return _scheme_world([ground] + balls), _scheme_camera()
+
+
+def scheme_chapter11a():
+    """scheme/chapter11a.scm:16-59 (golden only with the Scheme n1/n2 rule)."""
+    c = rt.color
+    ground = rt.plane().with_material(_smat(None, 1.0, 0.0, 0.0, 100.0, pattern=rt.checkers_pattern(c(0.8, 0.2, 0.2), c(0.2, 0.2, 0.8))))
+    ceiling = rt.plane().with_material(_smat((0.8, 0.8, 1), 1.0, 0.0, 0.0, 100.0)).with_transform(rt.translation(0, 11, 0))
+    left = rt.sphere().with_transform(rt.translation(-1.5, 1, 0.5)).with_material(_smat((0, 0, 0), 0.0, 0.0, 1.0, 200.0, 1.0, 0.0, 1.0))
+    right = rt.sphere().with_transform(rt.translation(1.5, 1, 0.5)).with_material(_smat((0, 0, 0), 0.0, 0.0, 1.0, 200.0, 0.0, 1.0, 1.5))
+    inner = rt.sphere().with_transform(rt.translation(1.5, 1, 0.5) * rt.scaling(0.5, 0.5, 0.5)).with_material(
+        _smat((0, 0, 0), 0.0, 0.0, 0.0, 200.0, 0.0, 1.0, 0.8))
+    return _scheme_world([ground, ceiling, right, inner, left]), _scheme_camera()
+
+
+def scheme_chapter11b():
+    """scheme/chapter11b.scm:16-49."""
+    c = rt.color
+    ground = rt.plane().with_material(_smat(None, 1.0, 0.0, 0.0, 100.0, pattern=rt.checkers_pattern(c(0.1, 0.4, 0.9), c(0.1, 0.2, 0.5)))
+                                      ).with_transform(rt.translation(0, -3, 0))
+    water = rt.plane().with_material(_smat((0, 0, 0), 1.0, 0.0, 0.0, 100.0, 0.0, 1.0, 1.33))
+    foliage = rt.sphere().with_material(_smat(None, 1.0, 0.0, 0.0, 100.0, pattern=rt.checkers_pattern(c(0.2, 0.6, 0.2), c(0.6, 0.4, 0.1))
+                                              .with_transform(rt.scaling(0.1, 0.1, 0.1)))).with_transform(rt.scaling(100, 100, 100))
+    sky = rt.plane().with_material(_smat((0.8, 0.8, 1), 1.0, 0.0, 0.0, 100.0)).with_transform(rt.translation(0, 11, 0))
+    return _scheme_world([ground, water, sky, foliage]), _scheme_camera((0, 0.5, 0), (0, 0.5, 1))
+
+
+def scheme_chapter13():
+    """scheme/chapter13.scm:15-58 (cylinders + a transparent capped cone; Scheme n1/n2 rule)."""
+    floor = rt.plane().with_material(_smat((1, 0.9, 0.9), 0.1, 0.9, 0.0, 100.0))
+    middle = rt.cylinder().with_transform(rt.translation(-0.5, 1, 0.5)).with_material(_smat((0.1, 1, 0.5), 0.1, 0.7, 0.3, 200.0))
+    right = rt.cylinder(-math.inf, 0.1, True).with_transform(rt.translation(1.5, 0.0, -0.5) * rt.scaling(0.5, 1.0, 0.5)).with_material(
+        _smat((0.5, 1, 0.1), 0.1, 0.7, 0.3, 200.0))
+    left = rt.cylinder(-math.inf, 1.0, False).with_transform(rt.translation(-1.5, 0.33, -0.75) * rt.scaling(0.33, 0.33, 0.33)).with_material(
+        _smat((1, 0.8, 0.1), 0.1, 0.7, 0.3, 200.0))
+    top = rt.cone(-1.5, -1.0, True).with_transform(rt.translation(0, 0.5, -0.75) * rt.scaling(0.2, 0.2, 0.2)).with_material(
+        _smat((0.9, 0.8, 0.7), 0.0, 0.5, 1.0, 200.0, 0.0, 0.5, 1.5))
+    return _scheme_world([floor, middle, right, left, top]), _scheme_camera()
+
+
+def scheme_chapter16():
+    """scheme/chapter16.scm:16-37 (CSG difference cube - sphere)."""
+    floor = rt.plane().with_material(_smat((1, 0.9, 0.9), 0.3, 0.9, 0.0, 100.0))
+    a = rt.cube().with_material(_smat((0.2, 0.5, 1), 0.3, 0.9, 0.2, 50.0))
+    b = rt.sphere().with_material(_smat((1, 0.5, 0.2), 0.3, 0.9, 0.2, 50.0)).with_transform(rt.translation(0.5, 0.5, -0.5))
+    c = rt.csg_difference(a, b).with_transform(rt.translation(0, 1, 0))
+    w = _scheme_world([floor, c], light=(-8, 10, -9))
+    w.finalize_scene()
+    return w, _scheme_camera((-1.5, 4, -5), (0, 1, 0))
+
+
+SCHEME_GOLDENS = {
+    # name: (builder, oracle uses the Scheme n1/n2 rule?)
+    "chapter07": (lambda: scheme_chapter08(shadows=False), False),
+    "chapter08": (scheme_chapter08, False),
+    "chapter09": (scheme_chapter09, False),
+    "chapter10": (scheme_chapter10, False),
+    "chapter11a": (scheme_chapter11a, True),
+    "chapter11b": (scheme_chapter11b, False),
+    "chapter13": (scheme_chapter13, True),
+    "chapter16": (scheme_chapter16, False),
+}
+
+BASELINE_SCENES = {
+    "ch07": chapter07,
+    "ch11a": chapter11a,
+    "ch11b": chapter11b,
+    "teapot": chapter15,
+    "soft": soft_shadow,
+    "dof": depth_of_field,
+    "dice": chapter16,
+}
