@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s (primary + secondary) of Camera::render at 3840x2160.
+
+Workload (BASELINE.json configs[1]): the reference's chapter-11a reflection/refraction scene
+(rust/examples/chapter-11a.rs), recursion depth 5, 3840x2160, adaptive multisampling as the example ships it
+(min 5 samples, allowed standard error 1e-2) on the seeded counter RNG.  A "step" is one full frame.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: one process per GPU under torch.distributed.run)
+
+N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
+gathers the rows to rank 0 with RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CU x 128 lanes x 2 x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--sampling", default="shipped", choices=["shipped", "1spp"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
+    return ap.parse_args()
+
+
+def workload_name(a):
+    names = {"ch07": "chapter-07 spheres, hard shadows", "ch11a": "chapter-11a reflection/refraction, depth 5",
+             "ch11b": "chapter-11b water reflection/refraction, depth 5", "teapot": "chapter-15 teapot mesh in host-built BVH",
+             "soft": "soft_shadow sphere light", "dof": "depth-of-field thin lens", "dice": "chapter-16 CSG dice + lens"}
+    samp = "adaptive multisampling as shipped" if a.sampling == "shipped" else "1 centred sample per pixel"
+    return "%s, %dx%d, %s" % (names[a.scene], a.width, a.height, samp)
+
+
+def cpu_baseline(world, cam, a, scenes):
+    """The oracle (a C/f64 port that keeps the reference's per-ray lists + recursion) timed on the host cores on a
+    bounded sample of the same frame: every k-th row, k chosen so the run takes about --cpu-seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from raytracing_amd import abi
+    threads = min(os.cpu_count() or 1, 16)
+    opts = abi.make_opts(seed=a.seed)
+    rays = lambda st: st["primary"] + st["reflection"] + st["refraction"] + st["shadow"]
+    v = cam.vsize()
+    stride = max(1, v // 16)  # probe: ~16 rows
+    t0 = time.perf_counter()
+    _, st = orc.render(world, cam, opts, n_threads=threads, row_stride=stride, row_offset=stride // 2)
+    dt = time.perf_counter() - t0
+    rows_probe = len(range(stride // 2, v, stride))
+    per_row = dt / max(rows_probe, 1)
+    rows_target = int(max(rows_probe, min(v, a.cpu_seconds / max(per_row, 1e-9))))
+    if rows_target > rows_probe * 2:
+        stride = max(1, v // rows_target)
+        t0 = time.perf_counter()
+        _, st = orc.render(world, cam, opts, n_threads=threads, row_stride=stride, row_offset=stride // 2)
+        dt = time.perf_counter() - t0
+    n_rows = len(range(stride // 2, v, stride))
+    return {"value": rays(st) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "every %d-th row (%d of %d rows) of the same %dx%d frame, same seed; %.1f s of CPU time on %d threads" % (
+                stride, n_rows, v, cam.hsize(), v, dt, threads)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import abi, scenes
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world_size != a.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    build = scenes.BASELINE_SCENES[a.scene]
+    world, cam = build(a.width, a.height, deterministic=(a.sampling == "1spp"))
+    scene = abi.Scene(world)
+    prec = 0 if a.precision == "f32" else 1
+    opts = abi.make_opts(seed=a.seed, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
+    h, v = cam.hsize(), cam.vsize()
+    my_rows = abi.rank_rows(v, rank, world_size, a.tile_rows)
+    max_rows = max(abi.rank_rows(v, r, world_size, a.tile_rows) for r in range(world_size))
+    local = torch.zeros((max_rows, h, 3), dtype=torch.float32, device=dev)
+    stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
+    gathered = [torch.zeros_like(local) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+
+    def step(timed_events=None):
+        if timed_events is not None:
+            timed_events[0].record()
+        abi.render_device(scene, cam, opts, local, stats, stream)
+        if timed_events is not None:
+            timed_events[1].record()
+        if world_size > 1:
+            dist.gather(local, gathered, dst=0)
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    stats.zero_()
+    kernel_ms = []
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(pairs[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = [p[0].elapsed_time(p[1]) for p in pairs]
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = stats.clone()
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    tot = tot.cpu().numpy()
+    st_local = stats.cpu().numpy()
+    S = {k: int(tot[i]) for i, k in enumerate(abi.STAT_NAMES)}
+    rays = S["primary"] + S["reflection"] + S["refraction"] + S["shadow"]
+
+    if rank == 0:
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        flops_launch = float(st_local[abi.STAT_NAMES.index("flops")]) / a.steps  # this rank's launch
+        achieved = flops_launch / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                with open(tp) as f:
+                    traffic = json.load(f).get("%s_%s" % (a.scene, a.sampling))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+secondary) at 3840x2160, 1/2/4/8 MI355X; % FP32 VALU peak",
+            "value": rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world_size,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": a.precision,
+            "data": "synthetic",
+            "config": {"workload": workload_name(a), "scene": a.scene, "max_depth": int(world.max_reflection_depth),
+                       "seed": a.seed, "sharding": "8-row tiles round-robin, RCCL gather to rank 0" if world_size > 1 else "none",
+                       "rays_per_step": rays // a.steps, "samples_per_step": S["samples"] // a.steps,
+                       "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                         "kernel": "render_kernel<float>" if prec == 0 else "render_kernel<double>", "kernel_ms": k_ms,
+                         "algorithmic_flops_per_launch": flops_launch,
+                         "note": "FP32 vector (VALU) roofline, no MFMA on this path; algorithmic FLOPs = reference "
+                                 "arithmetic per event (DESIGN.md 'FLOP accounting'), rank 0's launch"},
+        }
+        if not a.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(world, cam, a, scenes)
+        print(json.dumps(out), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,7 +185,10 @@ enum {
     RTMI_STAT_LEAF_TESTS = 5, /* primitive local_intersect evaluations                            */
     RTMI_STAT_NODE_VISITS = 6,/* Group / BoundingGroup / CSG nodes entered                        */
     RTMI_STAT_OVERFLOW = 7,   /* rays that hit a fixed device capacity (result may be wrong)      */
-    RTMI_N_STATS = 8
+    RTMI_STAT_FLOPS = 8,      /* algorithmic FLOPs of the events above, priced with the constants
+                                 of DESIGN.md "FLOP accounting"                         */
+    RTMI_STAT_AABB_TESTS = 9, /* slab tests                                                        */
+    RTMI_N_STATS = 10
 };
 
 typedef struct rtmi_stats {

@@ -820,7 +820,8 @@ static void fill_record(ctx_t *cx, const comps_t *c, rtmi_hit_record *rec) {
     rec->n1 = c->n1;
     rec->n2 = c->n2;
     rec->shadowed = -1.0;
-    if (cx->sc->n_lights > 0) {
+    int k0 = cx->sc->n_lights > 0 ? cx->sc->lights[0].kind : -1;
+    if (k0 == RTMI_LIGHT_POINT || k0 == RTMI_LIGHT_REALISTIC_POINT || k0 == RTMI_LIGHT_BEAM) {
         incoming_t in = incoming_at(&cx->sc->lights[0], c->over_point, 0.5, 0.5);
         if (in.kind == IL_RAY) rec->shadowed = is_shadowed(cx, &in, c->over_point);
     }

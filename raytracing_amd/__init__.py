@@ -12,6 +12,14 @@ There is no CPU fallback anywhere in this package: rendering needs ``librtmi.so`
 """
 import os as _os
 
+# torch wheels bundle their own libamdhip64; a process must not end up with two HIP runtimes (the second one
+# sees no GPU).  Importing torch first makes librtmi.so bind to the runtime torch already loaded.
+if not _os.environ.get("RTMI_NO_TORCH"):
+    try:
+        import torch as _torch  # noqa: F401
+    except ImportError:
+        _torch = None
+
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 
 try:

@@ -37,9 +37,14 @@ __device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long 
     if (!stats) return;
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) {
+        if (i == RTMI_STAT_FLOPS) continue;
         uint32_t s = wave_sum(st.c[i]);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
     }
+    unsigned long long f = st.flops;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
+    if ((threadIdx.x & 63) == 0 && f) atomicAdd(&stats[RTMI_STAT_FLOPS], f);
 }
 
 // Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310): one wave64 per 8x8 pixel tile,
@@ -50,6 +55,7 @@ __global__ void __launch_bounds__(64) render_kernel(DScene<R> sc, DCamera<R> cam
     Stats st;
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) st.c[i] = 0;
+    st.flops = 0;
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
     const int lane = threadIdx.x & 63;
@@ -80,6 +86,7 @@ __global__ void __launch_bounds__(64) render_kernel(DScene<R> sc, DCamera<R> cam
             }
             rng_begin(rng, pixel, s);
             st.c[RTMI_STAT_SAMPLES]++;
+            st.flops += camera_flops(cam);
             Ray<R> ray = ray_for_pixel(cam, x, y, s != 0, rng);
             V3<R> c = color_at<R>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
             sum = sum + c;
@@ -104,6 +111,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
     Stats st;
 #pragma unroll
     for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
+    st.flops = 0;
     Rng rng;
     rng.k0 = seed_lo; rng.k1 = seed_hi;
     rng_begin(rng, (uint32_t)i, 0);
@@ -396,6 +404,8 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
         memset(&p, 0, sizeof p);
         cp12(p.inv, s.inv); cp3(p.a, s.a); cp3(p.b, s.b);
         p.kind = s.kind;
+        static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        p.pad = memcmp(s.inv, ident, sizeof ident) != 0; // priced as a second transform in the FLOP accounting
     }
     std::vector<DLight<R>> lights((size_t)d->n_lights);
     for (int i = 0; i < d->n_lights; ++i) {

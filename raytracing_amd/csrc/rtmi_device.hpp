@@ -215,8 +215,27 @@ template <typename R> __device__ __forceinline__ R rng_next(Rng &g) {
 }
 
 struct Stats {
-    uint32_t c[RTMI_N_STATS];
+    uint32_t c[RTMI_N_STATS]; // c[RTMI_STAT_FLOPS] is unused: flops are summed in 64 bits below
+    unsigned long long flops;
 };
+
+// Algorithmic FLOP prices per event (mul/add/sub/div/sqrt/exp2/log2 = 1, FMA = 2, compares = 0),
+// derived from the cited reference lines.  They price the REFERENCE's arithmetic, not this kernel's.
+constexpr uint32_t F_XFORM = 33;       // ray -> object space (ray.rs:30-35)
+constexpr uint32_t F_SPHERE_MISS = 21, F_SPHERE_HIT = 29; // sphere.rs:50-60
+constexpr uint32_t F_PLANE = 3;        // plane.rs:36-41
+constexpr uint32_t F_CUBE = 20;        // cube.rs:34-44,78-79
+constexpr uint32_t F_CYL_OPEN = 30, F_CYL_CLOSED = 50; // cylinder.rs:42-49,80-104 (cone priced alike)
+constexpr uint32_t F_TRI_DET = 15, F_TRI_U = 24, F_TRI_V = 39, F_TRI_FULL = 45; // triangle.rs:240-264
+constexpr uint32_t F_AABB = 20;        // aabb.rs:46-70,134-135
+constexpr uint32_t F_PREPARE = 75, F_SMOOTH_NORMAL = 9; // ray.rs:77-84, shapes/mod.rs:262-264,320-321
+constexpr uint32_t F_LIGHT_RAY = 60, F_LIGHT_SHADOWED = 20, F_LIGHT_OMNI = 3; // lights.rs:90-94, materials.rs:256-285
+constexpr uint32_t F_COMBINE = 15;     // materials.rs:399-410
+constexpr uint32_t F_SCHLICK = 20;     // ray.rs:200-218
+constexpr uint32_t F_REFRACT_DIR = 25; // materials.rs:319-326
+constexpr uint32_t F_WEIGHT = 3;       // materials.rs:305,332
+constexpr uint32_t F_PATTERN_XF = 33, F_PATTERN_EVAL = 6; // shapes/mod.rs:268, pattern.rs:52,7-35
+constexpr uint32_t F_CAMERA = 50, F_CAMERA_LENS = 35;     // camera.rs:125-149
 
 // ---------------------------------------------------------------------------------------------
 // local_intersect per primitive kind (object space).  Roots come back ascending in t[0..n).
@@ -240,11 +259,13 @@ __device__ __forceinline__ void quad_roots(float a, float hb, float c, float dis
 }
 
 template <typename R>
-__device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> *tris, V3<R> o, V3<R> d, R t[4], R &u_out, R &v_out) {
+__device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> *tris, V3<R> o, V3<R> d, R t[4], R &u_out, R &v_out,
+                                               uint32_t &fl) {
     const R EPS = (R)RTMI_EPSILON;
     const R INF = Lim<R>::inf();
     uint32_t kind = g.kind & LEAF_KIND_MASK;
     int n = 0;
+    fl = 0;
     if (kind == RTMI_SPHERE) { // sphere.rs:47-63
         R a = dot(d, d), hb = dot(d, o);
         R disc4, c = dot(o, o) - (R)1;
@@ -255,12 +276,15 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         } else {
             disc4 = hb * hb - a * c;
         }
+        fl = F_SPHERE_MISS;
         if (!(disc4 < (R)0)) {
             quad_roots(a, hb, c, disc4, t[0], t[1]);
             cswap(t[0], t[1]);
             n = 2;
+            fl = F_SPHERE_HIT;
         }
     } else if (kind == RTMI_PLANE) { // plane.rs:35-44
+        fl = F_PLANE;
         if (!(abs_(d.y) < EPS)) { t[0] = -o.y / d.y; n = 1; }
     } else if (kind == RTMI_CUBE) { // cube.rs:33-46,74-85
         bool ok = true;
@@ -274,9 +298,11 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
             tmin = ax == 0 ? lo : max_(tmin, lo);
             tmax = ax == 0 ? hi : min_(tmax, hi);
         }
+        fl = F_CUBE;
         if (ok && tmin <= tmax) { t[0] = tmin; t[1] = tmax; n = 2; }
     } else if (kind == RTMI_CYLINDER || kind == RTMI_CONE) { // cylinder.rs:36-109, cone.rs:36-120
         const bool cone = kind == RTMI_CONE;
+        fl = (g.kind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
         R a = d.x * d.x + d.z * d.z, hb = o.x * d.x + o.z * d.z, c = o.x * o.x + o.z * o.z;
         if (cone) { a -= d.y * d.y; hb -= o.y * d.y; c -= o.y * o.y; } else { c -= (R)1; }
         R w0 = INF, w1 = INF, k0 = INF, k1 = INF; // wall roots, cap roots; +inf = absent
@@ -313,17 +339,21 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         V3<R> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         V3<R> dir_cross_e2 = cross(d, e2);
         R det = dot(e1, dir_cross_e2);
+        fl = F_TRI_DET;
         if (!(abs_(det) < EPS)) {
             R f = (R)1 / det;
             V3<R> p1_to_origin = o - ld3(tr.p1);
             R u = f * dot(p1_to_origin, dir_cross_e2);
+            fl = F_TRI_U;
             if (!(u < (R)0 || u > (R)1)) {
                 V3<R> origin_cross_e1 = cross(p1_to_origin, e1);
                 R v = f * dot(d, origin_cross_e1);
+                fl = F_TRI_V;
                 if (!(v < (R)0 || (u + v) > (R)1)) {
                     t[0] = f * dot(e2, origin_cross_e1);
                     u_out = u; v_out = v;
                     n = 1;
+                    fl = F_TRI_FULL;
                 }
             }
         }
@@ -360,9 +390,13 @@ __device__ __forceinline__ V3<R> local_normal(const DLeaf<R> &g, const DTri<R> *
 // World-space intersection of one leaf: Shape::intersect (shapes/mod.rs:252-255).  When the ray was
 // spawned on this very leaf, its root nearest to zero IS the spawn point (|t| ~ 1e-5): force it behind.
 template <typename R>
-__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, R t[4], R &u, R &v) {
+__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, R t[4], R &u, R &v,
+                                          Stats &st) {
     V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
-    int n = local_intersect(g, tris, o, d, t, u, v);
+    uint32_t fl;
+    int n = local_intersect(g, tris, o, d, t, u, v, fl);
+    st.c[RTMI_STAT_LEAF_TESTS]++;
+    st.flops += F_XFORM + fl;
     if (is_origin && n > 0) {
         int k = 0;
         R best = abs_(t[0]);
@@ -443,8 +477,7 @@ __device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray
         const DLeaf<R> &g = sc.leaves[li];
         if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) continue;
         R t[4], u, v;
-        st.c[RTMI_STAT_LEAF_TESTS]++;
-        int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v);
+        int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v, st);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < n) {
@@ -510,8 +543,7 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
                                            Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) return;
     R t[4], u = 0, v = 0;
-    st.c[RTMI_STAT_LEAF_TESTS]++;
-    int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v);
+    int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v, st);
     if (MODE == MODE_COLLECT) {
         int cnt = 0;
         R last_t = 0;
@@ -556,6 +588,8 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
             // negative-t roots for the in/out state); collect: anything in front of the hit counts
             R hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
             R lo = (MODE == MODE_COLLECT) ? -Lim<R>::inf() : (R)0;
+            st.c[RTMI_STAT_AABB_TESTS]++;
+            st.flops += F_AABB;
             if (!slab(nd, ray, lo, hi)) continue;
         }
         st.c[RTMI_STAT_NODE_VISITS]++;
@@ -789,11 +823,17 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             V3<R> over_point = c.point + c.normalv * EPS;
             // Phong::color_at (materials.rs:239-244): patterns are looked up at comps.point
             V3<R> surface_color = ld3(m.color);
-            if (m.pattern >= 0) surface_color = pattern_at(sc.patterns[m.pattern], xf_point(g.inv, c.point));
+            st.flops += F_PREPARE + (((g.kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) ? F_SMOOTH_NORMAL : 0u) + F_COMBINE;
+            if (m.pattern >= 0) {
+                const DPattern<R> &pat = sc.patterns[m.pattern];
+                surface_color = pattern_at(pat, xf_point(g.inv, c.point));
+                st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u);
+            }
             V3<R> surface = mk<R>(0, 0, 0);
             for (uint32_t li = 0; li < sc.n_lights; ++li) { // materials.rs:386-397
                 Incoming<R> in = incoming_at(sc.lights[li], over_point, rng);
                 bool in_shadow = is_shadowed(sc, in, over_point, h.leaf, st);
+                st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
             }
             surface = mk<R>(min_(max_(surface.x, (R)0), (R)1), min_(max_(surface.y, (R)0), (R)1), min_(max_(surface.z, (R)0), (R)1)); // :399
@@ -810,10 +850,12 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             R w_refl = weight * m.reflective, w_refr = weight * m.transparency;
             if (m.reflective > (R)0 && m.transparency > (R)0 && remaining > 0) { // materials.rs:406-408
                 R reflectance = schlick(c.eyev, c.normalv, c.n1, c.n2);
+                st.flops += F_SCHLICK;
                 w_refl *= reflectance;
                 w_refr *= (R)1 - reflectance;
             }
             Ray<R> refr_ray = ray;
+            st.flops += (do_refl ? F_WEIGHT : 0u) + (do_refr ? F_WEIGHT + F_REFRACT_DIR : 0u);
             if (do_refr) { // materials.rs:319-326
                 R n_ratio = c.n1 / c.n2;
                 R cos_i = dot(c.eyev, c.normalv);
@@ -856,6 +898,9 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
 }
 
 // Camera::ray_for_pixel (camera.rs:120-153)
+template <typename R> __device__ __forceinline__ uint32_t camera_flops(const DCamera<R> &cam) {
+    return F_CAMERA + (cam.aperture_size == (R)0 ? 0u : F_CAMERA_LENS);
+}
 template <typename R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera<R> &cam, int px, int py, bool randomize, Rng &rng) {
     R jx = (R)0.5, jy = (R)0.5;
     if (randomize) { jx = rng_next<R>(rng); jy = rng_next<R>(rng); }

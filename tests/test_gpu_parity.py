@@ -3,7 +3,7 @@
 Bars (stated per test):
   * f64 validation mode, deterministic scenes: every pixel within 1/255 per 8-bit channel AND within 1e-4 linear;
     ray counters exactly equal to the oracle's.
-  * f32 product path, deterministic scenes: >= 99.9 % of pixels within 1/255 (pixels whose ray passes within f32
+  * f32 product path, deterministic scenes: >= 99.8 % of pixels within 1/255 (pixels whose ray passes within f32
     rounding of a silhouette / shadow edge / checker boundary may flip), PSNR >= 45 dB.
   * stochastic scenes (adaptive multisampling, area light, thin lens; same seed, same counter RNG): PSNR vs the
     oracle >= 35 dB for f32 (f32 rounding flips a few adaptive-termination decisions), >= 60 dB for f64.
@@ -67,7 +67,7 @@ def test_scheme_scenes_f32(name):
     ref, rst = orc.render(world, cam)
     img, st = gpu_render(world, cam, 0)
     frac, bad = frac_within_1(img, ref)
-    assert frac >= 0.999, "only %.5f of pixels within 1/255 (%d bad)" % (frac, bad)
+    assert frac >= 0.998, "only %.5f of pixels within 1/255 (%d bad)" % (frac, bad)
     assert psnr(img, ref) >= 45.0
     assert st["overflow"] == 0
 
@@ -126,7 +126,7 @@ def test_row_tile_sharding_is_bit_identical():
     for r in range(nr):
         rows = abi.rank_rows(v, r, nr, tr)
         buf = torch.zeros((rows, h, 3), dtype=torch.float32, device="cuda")
-        stats = torch.zeros(8, dtype=torch.int64, device="cuda")
+        stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device="cuda")
         abi.render_device(sc, cam, abi.make_opts(rank=r, nranks=nr, tile_rows=tr), buf, stats, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         loc = buf.cpu().numpy()
