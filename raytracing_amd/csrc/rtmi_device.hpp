@@ -260,7 +260,7 @@ __device__ __forceinline__ void quad_roots(float a, float hb, float c, float dis
 
 template <typename R>
 __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> *tris, V3<R> o, V3<R> d, R t[4], R &u_out, R &v_out,
-                                               uint32_t &fl) {
+                                               uint32_t &fl, R &det_out) {
     const R EPS = (R)RTMI_EPSILON;
     const R INF = Lim<R>::inf();
     uint32_t kind = g.kind & LEAF_KIND_MASK;
@@ -339,6 +339,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         V3<R> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         V3<R> dir_cross_e2 = cross(d, e2);
         R det = dot(e1, dir_cross_e2);
+        det_out = det; // = d . (e2 x e1): the side of the geometric normal the ray travels towards
         fl = F_TRI_DET;
         if (!(abs_(det) < EPS)) {
             R f = (R)1 / det;
@@ -387,14 +388,23 @@ __device__ __forceinline__ V3<R> local_normal(const DLeaf<R> &g, const DTri<R> *
     return normalize(ld3(tr.n2) * u + ld3(tr.n3) * v + ld3(tr.n1) * ((R)1 - u - v));
 }
 
-// World-space intersection of one leaf: Shape::intersect (shapes/mod.rs:252-255).  When the ray was
-// spawned on this very leaf, its root nearest to zero IS the spawn point (|t| ~ 1e-5): force it behind.
+// How a ray was spawned on its origin leaf (bits above the leaf index in Ray bookkeeping)
+constexpr uint32_t SIDE_PLUS = 1u; // smooth triangles: the spawn point lies on the +(e2 x e1) side of the triangle's plane
+
+// World-space intersection of one leaf: Shape::intersect (shapes/mod.rs:252-255).  When the ray was spawned on
+// this very leaf, its root nearest to zero IS the spawn point (|t| ~ 1e-5) and its sign is known analytically:
+//  * geometric normals (everything but smooth triangles): the spawn point was pushed off the surface along the
+//    normal the ray leaves on, so that root is behind the origin;
+//  * smooth triangles: the push is along the INTERPOLATED normal, so a ray may start on one side of the flat
+//    triangle and head for the other (the reference's shadow-terminator artefact, which must be kept): the root is
+//    in front iff the ray travels towards the plane, i.e. sign(d . n_g) differs from the side it started on.
 template <typename R>
-__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, R t[4], R &u, R &v,
-                                          Stats &st) {
+__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, uint32_t origin_side,
+                                          R t[4], R &u, R &v, Stats &st) {
     V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
     uint32_t fl;
-    int n = local_intersect(g, tris, o, d, t, u, v, fl);
+    R det = 0;
+    int n = local_intersect(g, tris, o, d, t, u, v, fl, det);
     st.c[RTMI_STAT_LEAF_TESTS]++;
     st.flops += F_XFORM + fl;
     if (is_origin && n > 0) {
@@ -404,6 +414,11 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris
         for (int i = 1; i < 4; ++i)
             if (i < n && abs_(t[i]) < best) { best = abs_(t[i]); k = i; }
         R forced = -max_(best, (R)1e-30);
+        if ((g.kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) {
+            bool plus = (origin_side & SIDE_PLUS) != 0;
+            bool towards = plus ? det < (R)0 : det > (R)0;
+            if (towards) forced = -forced;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i == k) t[i] = forced;
@@ -468,7 +483,7 @@ template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op
 // buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
 // its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
 template <typename R, int MODE>
-__device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray, uint32_t origin_leaf, Hit<R> &best, R t_limit,
+__device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     R bt[CSG_BUF];
     uint32_t bid[CSG_BUF];
@@ -477,7 +492,7 @@ __device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray
         const DLeaf<R> &g = sc.leaves[li];
         if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) continue;
         R t[4], u, v;
-        int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v, st);
+        int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < n) {
@@ -540,10 +555,10 @@ __device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray
 // One leaf that is not under any CSG operator.
 template <typename R, int MODE>
 __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, const DLeaf<R> &g, const Ray<R> &ray, uint32_t origin_leaf,
-                                           Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+                                           uint32_t origin_side, Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) return;
     R t[4], u = 0, v = 0;
-    int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, t, u, v, st);
+    int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
     if (MODE == MODE_COLLECT) {
         int cnt = 0;
         R last_t = 0;
@@ -569,11 +584,11 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
 //   MODE_ANY    : best.leaf != NONE iff some shadow-casting root lies in [0, t_limit)
 //   MODE_COLLECT: open = which leaves the ray is inside of just in front of (t_limit, hit_leaf, hit_ord)
 template <typename R, int MODE>
-__device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, Hit<R> &best, R t_limit, uint32_t hit_leaf,
-                         uint32_t hit_ord, Open<R> &open, Stats &st) {
+__device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
+                         uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     // top-level primitives: wave-uniform loop bounds -> leaf records come in through scalar loads
     for (uint32_t li = 0; li < sc.root_leaf_count; ++li) {
-        plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+        plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         if (MODE == MODE_ANY && best.leaf != NONE) return;
     }
     if (sc.root_child_count == 0) return;
@@ -594,10 +609,10 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
         }
         st.c[RTMI_STAT_NODE_VISITS]++;
         if (nd.flags & NODE_CSGROOT) {
-            csg_root<R, MODE>(sc, nd, ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+            csg_root<R, MODE>(sc, nd, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         } else {
             for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li)
-                plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+                plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             for (uint32_t c = nd.child_count; c-- > 0;) {
                 if (sp < NODE_STACK) stack[sp++] = nd.child_first + c;
                 else st.c[RTMI_STAT_OVERFLOW] = 1;
@@ -731,6 +746,7 @@ template <typename R> __device__ __forceinline__ R schlick(V3<R> eyev, V3<R> nor
 template <typename R> struct Comps {
     V3<R> point, eyev, normalv;
     bool inside;
+    bool side_plus; // smooth triangles: normalv points to the +(e2 x e1) side of the flat triangle
     R n1, n2;
 };
 
@@ -741,10 +757,12 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
     c.eyev = -ray.d;
     V3<R> obj_point = xf_point(g.inv, c.point);
     R u = 0, v = 0;
+    V3<R> ng = mk<R>(0, 0, 0);
     if ((g.kind & LEAF_KIND_MASK) >= RTMI_TRIANGLE) { // barycentrics of the hit (triangle.rs:250,257)
         const DTri<R> &tr = sc.tris[g.tri];
         V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d);
         V3<R> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+        ng = cross(e2, e1);
         V3<R> dir_cross_e2 = cross(d, e2);
         R f = (R)1 / dot(e1, dir_cross_e2);
         V3<R> p1_to_origin = o - ld3(tr.p1);
@@ -754,6 +772,7 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
     V3<R> n = normalize(xf_normal(g.inv, local_normal(g, sc.tris, obj_point, u, v))); // shapes/mod.rs:261-265,319-322
     c.inside = dot(n, c.eyev) < (R)0;
     c.normalv = c.inside ? -n : n;
+    c.side_plus = dot(xf_vector(g.inv, c.normalv), ng) > (R)0;
     c.n1 = (R)1; c.n2 = (R)1;
 }
 
@@ -761,12 +780,12 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
 // the hit iff an odd number of its intersections precede the hit, and containers.last() is the open
 // leaf that was entered last (largest entry t).
 template <typename R>
-__device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, const Hit<R> &h, Comps<R> &c,
-                                             Stats &st) {
+__device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
+                                             const Hit<R> &h, Comps<R> &c, Stats &st) {
     Open<R> open;
     open.best = NONE; open.other = NONE; open.best_t = 0; open.other_t = 0; open.hit_parity = 0;
     Hit<R> dummy = {Lim<R>::inf(), NONE, 0};
-    traverse<R, MODE_COLLECT>(sc, ray, origin_leaf, dummy, h.t, h.leaf, h.ord, open, st);
+    traverse<R, MODE_COLLECT>(sc, ray, origin_leaf, origin_side, dummy, h.t, h.leaf, h.ord, open, st);
     c.n1 = open.best != NONE ? sc.materials[sc.leaves[open.best].material].ior : (R)1;
     if (open.hit_parity & 1u) c.n2 = open.other != NONE ? sc.materials[sc.leaves[open.other].material].ior : (R)1;
     else c.n2 = sc.materials[sc.leaves[h.leaf].material].ior;
@@ -776,12 +795,13 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
     V3<R> o, d;
     R weight;
     int32_t remaining;
-    uint32_t origin_leaf;
+    uint32_t origin_leaf, origin_side;
 };
 
 // World::is_shadowed (world.rs:172-180)
 template <typename R>
-__device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<R> &in, V3<R> p, uint32_t origin_leaf, Stats &st) {
+__device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<R> &in, V3<R> p, uint32_t origin_leaf, uint32_t origin_side,
+                                            Stats &st) {
     if (in.kind == IL_OMNI) return false;
     if (in.kind == IL_NOLIGHT) return true;
     st.c[RTMI_STAT_SHADOW]++;
@@ -790,7 +810,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
     R dist = sqrt_(dot(to_light, to_light));
     Hit<R> sh = {Lim<R>::inf(), NONE, 0};
     Open<R> unused;
-    traverse<R, MODE_ANY>(sc, sray, origin_leaf, sh, dist, NONE, 0, unused, st);
+    traverse<R, MODE_ANY>(sc, sray, origin_leaf, origin_side, sh, dist, NONE, 0, unused, st);
     return sh.leaf != NONE;
 }
 
@@ -802,7 +822,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
     const R EPS = (R)RTMI_EPSILON;
     V3<R> acc = mk<R>(0, 0, 0);
     R weight = (R)1;
-    uint32_t origin_leaf = NONE;
+    uint32_t origin_leaf = NONE, origin_side = 0;
     int cls = RTMI_STAT_PRIMARY;
     Pending<R> stack[MAX_DEPTH];
     int sp = 0;
@@ -813,7 +833,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
         else st.c[RTMI_STAT_REFRACTION]++;
         Hit<R> h = {Lim<R>::inf(), NONE, 0};
         Open<R> unused;
-        traverse<R, MODE_CLOSEST>(sc, ray, origin_leaf, h, Lim<R>::inf(), NONE, 0, unused, st);
+        traverse<R, MODE_CLOSEST>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
         bool spawned = false;
         if (h.leaf != NONE) {
             Comps<R> c;
@@ -832,7 +852,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             V3<R> surface = mk<R>(0, 0, 0);
             for (uint32_t li = 0; li < sc.n_lights; ++li) { // materials.rs:386-397
                 Incoming<R> in = incoming_at(sc.lights[li], over_point, rng);
-                bool in_shadow = is_shadowed(sc, in, over_point, h.leaf, st);
+                bool in_shadow = is_shadowed(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
                 st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
             }
@@ -842,7 +862,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             bool want_n = first_comps && first;
             bool do_refl = !(m.reflective == (R)0) && remaining > 0;   // materials.rs:297
             bool do_refr = !(m.transparency == (R)0) && remaining > 0; // materials.rs:316
-            if (do_refr || want_n) collect_n1n2(sc, ray, origin_leaf, h, c, st);
+            if (do_refr || want_n) collect_n1n2(sc, ray, origin_leaf, origin_side, h, c, st);
             if (first) {
                 if (first_hit) *first_hit = h;
                 if (first_comps) *first_comps = c;
@@ -872,15 +892,16 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
                 if (do_refr && sp < MAX_DEPTH) {
                     stack[sp].o = refr_ray.o; stack[sp].d = refr_ray.d; stack[sp].weight = w_refr;
                     stack[sp].remaining = remaining - 1; stack[sp].origin_leaf = h.leaf;
+                    stack[sp].origin_side = c.side_plus ? 0u : SIDE_PLUS; // under_point: the other side
                     ++sp;
                 }
                 ray.d = ray.d - c.normalv * ((R)2 * dot(ray.d, c.normalv)); // reflectv, ray.rs:84
                 ray.o = over_point;
-                weight = w_refl; remaining -= 1; origin_leaf = h.leaf; cls = RTMI_STAT_REFLECTION;
+                weight = w_refl; remaining -= 1; origin_leaf = h.leaf; origin_side = c.side_plus ? SIDE_PLUS : 0u; cls = RTMI_STAT_REFLECTION;
                 spawned = true;
             } else if (do_refr) {
                 ray = refr_ray;
-                weight = w_refr; remaining -= 1; origin_leaf = h.leaf; cls = RTMI_STAT_REFRACTION;
+                weight = w_refr; remaining -= 1; origin_leaf = h.leaf; origin_side = c.side_plus ? 0u : SIDE_PLUS; cls = RTMI_STAT_REFRACTION;
                 spawned = true;
             }
         } else if (first && first_hit) {
@@ -891,7 +912,8 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             if (sp == 0) break;
             --sp;
             ray.o = stack[sp].o; ray.d = stack[sp].d; weight = stack[sp].weight;
-            remaining = stack[sp].remaining; origin_leaf = stack[sp].origin_leaf; cls = RTMI_STAT_REFRACTION;
+            remaining = stack[sp].remaining; origin_leaf = stack[sp].origin_leaf; origin_side = stack[sp].origin_side;
+            cls = RTMI_STAT_REFRACTION;
         }
     }
     return acc;
@@ -900,6 +922,15 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
 // Camera::ray_for_pixel (camera.rs:120-153)
 template <typename R> __device__ __forceinline__ uint32_t camera_flops(const DCamera<R> &cam) {
     return F_CAMERA + (cam.aperture_size == (R)0 ? 0u : F_CAMERA_LENS);
+}
+template <typename R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera<R> &cam, int px, int py, bool randomize, Rng &rng);
+// The camera ray is always generated in f64 and then rounded to R: world_y = half_height - y_offset and the view
+// rotation cancel to ~1e-4 for rays that graze the horizon, and an f32 error there moves the hit on a ground plane by
+// whole checker cells (t ~ 1/d_y).  ~85 f64 FLOPs per sample against thousands of f32 FLOPs of tracing.
+template <typename R> __device__ __forceinline__ Ray<R> camera_ray(const DCamera<double> &cam, int px, int py, bool randomize, Rng &rng) {
+    Ray<double> r = ray_for_pixel<double>(cam, px, py, randomize, rng);
+    Ray<R> q = {mk<R>((R)r.o.x, (R)r.o.y, (R)r.o.z), mk<R>((R)r.d.x, (R)r.d.y, (R)r.d.z)};
+    return q;
 }
 template <typename R> __device__ __forceinline__ Ray<R> ray_for_pixel(const DCamera<R> &cam, int px, int py, bool randomize, Rng &rng) {
     R jx = (R)0.5, jy = (R)0.5;
