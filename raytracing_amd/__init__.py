@@ -31,6 +31,6 @@ except ImportError as e:  # fail loudly: the native extension IS the product
         "`make -C raytracing_amd/csrc` (needs hipcc + pybind11)." % (e,)
     ) from e
 
-LIB_PATH = _os.path.join(_HERE, "librtmi.so")
+LIB_PATH = _os.environ.get("RTMI_LIB") or _os.path.join(_HERE, "librtmi.so")  # RTMI_LIB: A/B builds of the same ABI
 PRECISION_F32 = 0
 PRECISION_F64 = 1

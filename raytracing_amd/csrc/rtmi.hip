@@ -11,6 +11,10 @@
 
 using namespace rtmi_dev;
 
+#ifndef RTMI_WAVES
+#define RTMI_WAVES 3 // minimum waves per SIMD the render kernels are register-allocated for
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------
@@ -53,11 +57,11 @@ template <typename R> __device__ __forceinline__ bool need_more(const DCamera<do
     if (cnt == 0) return true;
     if (cam.max_samples > 0 && cnt >= (uint32_t)cam.max_samples) return false;
     if (n < (R)cam.min_samples) return true;
-    R inv_n = (R)1 / n;
+    R inv_n = rcp_(n);
     V3<R> mean = sum * inv_n;
     V3<R> var = sos * inv_n - had(mean, mean);
-    R variance = (var.x + var.y + var.z) / (R)3;
-    return variance / n > (R)cam.se2;
+    R variance = div_(var.x + var.y + var.z, (R)3);
+    return div_(variance, n) > (R)cam.se2;
 }
 
 template <typename R> __device__ __forceinline__ V3<R> shfl3(V3<R> v, int src) {
@@ -84,8 +88,8 @@ __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 // pixel, and compute that pixel's next G samples (counter RNG: sample s of a pixel is independent of who computes
 // it); a prefix sum over the group in sample order then finds the first sample count at which the reference's
 // loop would have stopped, and samples past it are discarded - their rays are not counted either.
-template <typename R>
-__global__ void __launch_bounds__(64) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+template <typename R, bool TREE>
+__global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *stats) {
     Stats st;
     stats_zero(st);
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(64) render_kernel(DScene<R> sc, DCamera<double
                 ls.c[RTMI_STAT_SAMPLES] = 1;
                 ls.flops = camera_flops(cam);
                 Ray<R> ray = camera_ray<R>(cam, ox, oy, s != 0, rng);
-                c = color_at<R>(sc, ray, (int)sc.max_depth, rng, ls, nullptr, nullptr);
+                c = color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, ls, nullptr, nullptr);
             }
             // inclusive prefix sums over the group, in sample order
             V3<R> ps = c, pq = had(c, c);
@@ -196,7 +200,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
     Comps<R> c;
     c.point = mk<R>(0, 0, 0); c.normalv = c.point; c.eyev = c.point; c.inside = false; c.side_plus = false; c.n1 = 1; c.n2 = 1;
     int rem = remaining ? remaining[i] : (int)sc.max_depth;
-    V3<R> col = color_at<R>(sc, ray, rem, rng, st, &h, &c);
+    V3<R> col = color_at<R, true>(sc, ray, rem, rng, st, &h, &c);
     if (rgb) { rgb[3 * i] = (double)col.x; rgb[3 * i + 1] = (double)col.y; rgb[3 * i + 2] = (double)col.z; }
     if (recs) {
         rtmi_hit_record r;
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
                 if (k == RTMI_LIGHT_POINT || k == RTMI_LIGHT_REALISTIC_POINT || k == RTMI_LIGHT_BEAM) {
                     V3<R> over_point = c.point + c.normalv * (R)RTMI_EPSILON;
                     Incoming<R> in = incoming_at(sc.lights[0], over_point, rng);
-                    if (in.kind == IL_RAY) r.shadowed = is_shadowed(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st) ? 1.0 : 0.0;
+                    if (in.kind == IL_RAY) r.shadowed = is_shadowed<R, true>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st) ? 1.0 : 0.0;
                 }
             }
         }
@@ -637,8 +641,16 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     int grid = std::min(rp.n_tiles, s->num_cu * 32);
     bool f64 = o && o->precision == RTMI_PRECISION_F64;
     if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
-    if (f64) hipLaunchKernelGGL(render_kernel<double>, dim3(grid), dim3(64), 0, st, s->h64, make_camera<double>(c, o), rp, d_out, (unsigned long long *)d_stats);
-    else hipLaunchKernelGGL(render_kernel<float>, dim3(grid), dim3(64), 0, st, s->h32, make_camera<double>(c, o), rp, d_out, (unsigned long long *)d_stats);
+    const bool tree = s->h32.root_child_count != 0;
+    DCamera<double> cam = make_camera<double>(c, o);
+    unsigned long long *ds = (unsigned long long *)d_stats;
+    if (f64) {
+        if (tree) hipLaunchKernelGGL((render_kernel<double, true>), dim3(grid), dim3(64), 0, st, s->h64, cam, rp, d_out, ds);
+        else hipLaunchKernelGGL((render_kernel<double, false>), dim3(grid), dim3(64), 0, st, s->h64, cam, rp, d_out, ds);
+    } else {
+        if (tree) hipLaunchKernelGGL((render_kernel<float, true>), dim3(grid), dim3(64), 0, st, s->h32, cam, rp, d_out, ds);
+        else hipLaunchKernelGGL((render_kernel<float, false>), dim3(grid), dim3(64), 0, st, s->h32, cam, rp, d_out, ds);
+    }
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }

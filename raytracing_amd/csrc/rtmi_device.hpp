@@ -144,9 +144,15 @@ template <typename R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { retur
 template <typename R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+// f32: the hardware's 1-ulp v_rcp / v_sqrt / v_rsq instead of the ~10-instruction correctly rounded sequences
+// (the path is VALU-bound and carries ~1e-7 relative error anyway); f64: IEEE division and sqrt, like the oracle.
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp_(double x) { return 1.0 / x; }
+__device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double div_(double a, double b) { return a / b; }
+__device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
-__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
@@ -252,10 +258,10 @@ __device__ __forceinline__ void quad_roots(double a, double hb, double c, double
     t1 = -(b - sq) / (2.0 * a);
 }
 __device__ __forceinline__ void quad_roots(float a, float hb, float c, float disc4, float &t0, float &t1) {
-    float sq = sqrtf(disc4);
+    float sq = sqrt_(disc4);
     float q = -(hb + copysignf(sq, hb));
-    t0 = q / a;
-    t1 = (q != 0.0f) ? c / q : t0;
+    t0 = div_(q, a);
+    t1 = (q != 0.0f) ? div_(c, q) : t0;
 }
 
 template <typename R>
@@ -271,7 +277,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         R disc4, c = dot(o, o) - (R)1;
         if constexpr (sizeof(R) == 4) {
             // |o - (hb/a) d|^2 avoids the b^2 - 4ac cancellation for distant origins
-            V3<R> l = o - d * (hb / a);
+            V3<R> l = o - d * div_(hb, a);
             disc4 = a * ((R)1 - dot(l, l));
         } else {
             disc4 = hb * hb - a * c;
@@ -285,7 +291,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         }
     } else if (kind == RTMI_PLANE) { // plane.rs:35-44
         fl = F_PLANE;
-        if (!(abs_(d.y) < EPS)) { t[0] = -o.y / d.y; n = 1; }
+        if (!(abs_(d.y) < EPS)) { t[0] = div_(-o.y, d.y); n = 1; }
     } else if (kind == RTMI_CUBE) { // cube.rs:33-46,74-85
         bool ok = true;
         R tmin = -INF, tmax = INF;
@@ -293,7 +299,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             if (dd[ax] == (R)0 && (oo[ax] < (R)-1 || oo[ax] > (R)1)) ok = false;
-            R a0 = ((R)-1 - oo[ax]) / dd[ax], a1 = ((R)1 - oo[ax]) / dd[ax];
+            R a0 = div_((R)-1 - oo[ax], dd[ax]), a1 = div_((R)1 - oo[ax], dd[ax]);
             R lo = a0 > a1 ? a1 : a0, hi = a0 > a1 ? a0 : a1;
             tmin = ax == 0 ? lo : max_(tmin, lo);
             tmax = ax == 0 ? hi : min_(tmax, hi);
@@ -309,7 +315,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         bool caps = true;
         if (abs_(a) < EPS) {
             // cone only: one root when b != 0 (cone.rs:88-97); the reference's b is 2*hb
-            if (cone && !(abs_((R)2 * hb) < EPS)) { w0 = c / ((R)-2 * ((R)2 * hb)); ++n; }
+            if (cone && !(abs_((R)2 * hb) < EPS)) { w0 = div_(c, (R)-2 * ((R)2 * hb)); ++n; }
         } else {
             R disc4 = hb * hb - a * c;
             if (disc4 < (R)0) {
@@ -324,7 +330,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
             }
         }
         if (caps && (g.kind & LEAF_CLOSED) && abs_(d.y) > EPS) { // intersect_caps
-            R tc0 = (g.minimum - o.y) / d.y, tc1 = (g.maximum - o.y) / d.y;
+            R tc0 = div_(g.minimum - o.y, d.y), tc1 = div_(g.maximum - o.y, d.y);
             R r0 = cone ? g.minimum * g.minimum : (R)1, r1 = cone ? g.maximum * g.maximum : (R)1;
             R x0 = o.x + tc0 * d.x, z0 = o.z + tc0 * d.z;
             if (x0 * x0 + z0 * z0 <= r0) { k0 = tc0; ++n; }
@@ -342,7 +348,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         det_out = det; // = d . (e2 x e1): the side of the geometric normal the ray travels towards
         fl = F_TRI_DET;
         if (!(abs_(det) < EPS)) {
-            R f = (R)1 / det;
+            R f = rcp_(det);
             V3<R> p1_to_origin = o - ld3(tr.p1);
             R u = f * dot(p1_to_origin, dir_cross_e2);
             fl = F_TRI_U;
@@ -437,7 +443,7 @@ template <typename R> __device__ __forceinline__ bool slab(const DNode &nd, cons
     for (int ax = 0; ax < 3; ++ax) {
         R lo = (R)nd.bmin[ax], hi = (R)nd.bmax[ax];
         if (d[ax] == (R)0 && (o[ax] < lo || o[ax] > hi)) ok = false;
-        R a0 = (lo - o[ax]) / d[ax], a1 = (hi - o[ax]) / d[ax];
+        R a0 = div_(lo - o[ax], d[ax]), a1 = div_(hi - o[ax], d[ax]);
         tmin = max_(tmin, min_(a0, a1));
         tmax = min_(tmax, max_(a0, a1));
     }
@@ -583,7 +589,7 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
 //   MODE_CLOSEST: best = min t >= 0.            t_limit = +inf
 //   MODE_ANY    : best.leaf != NONE iff some shadow-casting root lies in [0, t_limit)
 //   MODE_COLLECT: open = which leaves the ray is inside of just in front of (t_limit, hit_leaf, hit_ord)
-template <typename R, int MODE>
+template <typename R, int MODE, bool TREE>
 __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     // top-level primitives: wave-uniform loop bounds -> leaf records come in through scalar loads
@@ -591,6 +597,7 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
         plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         if (MODE == MODE_ANY && best.leaf != NONE) return;
     }
+    if (!TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
     if (sc.root_child_count == 0) return;
     uint32_t stack[NODE_STACK];
     int sp = 0;
@@ -670,7 +677,7 @@ template <typename R> __device__ __forceinline__ Incoming<R> incoming_at(const D
     case RTMI_LIGHT_REALISTIC_POINT: { // lights.rs:153-160
         V3<R> d = pos - p;
         in.direction = normalize(d);
-        in.color = in.color * ((R)1 / (FOUR_PI * dot(d, d)));
+        in.color = in.color * rcp_(FOUR_PI * dot(d, d));
         break;
     }
     case RTMI_LIGHT_BEAM: { // lights.rs:230-243
@@ -700,7 +707,7 @@ template <typename R> __device__ __forceinline__ Incoming<R> incoming_at(const D
         V3<R> d = in.origin - p;
         in.direction = normalize(d);
         R cosn = max_(dot(-in.direction, ld3(l.normal)), (R)0);
-        in.color = (in.color * cosn) * ((R)1 / (FOUR_PI * dot(d, d)));
+        in.color = (in.color * cosn) * rcp_(FOUR_PI * dot(d, d));
         break;
     }
     default: in.kind = IL_NOLIGHT;
@@ -729,12 +736,12 @@ __device__ __forceinline__ V3<R> lighting(const DMaterial<R> &m, V3<R> surface_c
 template <typename R> __device__ __forceinline__ R schlick(V3<R> eyev, V3<R> normalv, R n1, R n2) {
     R cos_en = dot(eyev, normalv);
     if (n1 > n2) {
-        R n = n1 / n2;
+        R n = div_(n1, n2);
         R sin2_t = n * n * ((R)1 - cos_en * cos_en);
         if (sin2_t > (R)1) return (R)1;
         cos_en = sqrt_((R)1 - sin2_t);
     }
-    R r0 = (n1 - n2) / (n1 + n2);
+    R r0 = div_(n1 - n2, n1 + n2);
     r0 = r0 * r0;
     R tmp = (R)1 - cos_en, tmp2 = tmp * tmp;
     return r0 + ((R)1 - r0) * (tmp2 * tmp2 * tmp);
@@ -764,7 +771,7 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
         V3<R> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         ng = cross(e2, e1);
         V3<R> dir_cross_e2 = cross(d, e2);
-        R f = (R)1 / dot(e1, dir_cross_e2);
+        R f = rcp_(dot(e1, dir_cross_e2));
         V3<R> p1_to_origin = o - ld3(tr.p1);
         u = f * dot(p1_to_origin, dir_cross_e2);
         v = f * dot(d, cross(p1_to_origin, e1));
@@ -779,13 +786,13 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
 // compute_refractive_indices (ray.rs:104-140) without the sorted list: a leaf is "open" in front of
 // the hit iff an odd number of its intersections precede the hit, and containers.last() is the open
 // leaf that was entered last (largest entry t).
-template <typename R>
+template <typename R, bool TREE>
 __device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
                                              const Hit<R> &h, Comps<R> &c, Stats &st) {
     Open<R> open;
     open.best = NONE; open.other = NONE; open.best_t = 0; open.other_t = 0; open.hit_parity = 0;
     Hit<R> dummy = {Lim<R>::inf(), NONE, 0};
-    traverse<R, MODE_COLLECT>(sc, ray, origin_leaf, origin_side, dummy, h.t, h.leaf, h.ord, open, st);
+    traverse<R, MODE_COLLECT, TREE>(sc, ray, origin_leaf, origin_side, dummy, h.t, h.leaf, h.ord, open, st);
     c.n1 = open.best != NONE ? sc.materials[sc.leaves[open.best].material].ior : (R)1;
     if (open.hit_parity & 1u) c.n2 = open.other != NONE ? sc.materials[sc.leaves[open.other].material].ior : (R)1;
     else c.n2 = sc.materials[sc.leaves[h.leaf].material].ior;
@@ -799,7 +806,7 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
 };
 
 // World::is_shadowed (world.rs:172-180)
-template <typename R>
+template <typename R, bool TREE>
 __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<R> &in, V3<R> p, uint32_t origin_leaf, uint32_t origin_side,
                                             Stats &st) {
     if (in.kind == IL_OMNI) return false;
@@ -810,14 +817,14 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
     R dist = sqrt_(dot(to_light, to_light));
     Hit<R> sh = {Lim<R>::inf(), NONE, 0};
     Open<R> unused;
-    traverse<R, MODE_ANY>(sc, sray, origin_leaf, origin_side, sh, dist, NONE, 0, unused, st);
+    traverse<R, MODE_ANY, TREE>(sc, sray, origin_leaf, origin_side, sh, dist, NONE, 0, unused, st);
     return sh.leaf != NONE;
 }
 
 // World::color_at (world.rs:115-118) with Phong::shade_hit (materials.rs:371-412) unrolled into a loop:
 // shade_hit is linear in its children's colours, so each ray carries the product of the factors
 // above it ("weight") and adds weight * (clipped direct light + emissive) to the sample.
-template <typename R>
+template <typename R, bool TREE>
 __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
     const R EPS = (R)RTMI_EPSILON;
     V3<R> acc = mk<R>(0, 0, 0);
@@ -833,7 +840,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
         else st.c[RTMI_STAT_REFRACTION]++;
         Hit<R> h = {Lim<R>::inf(), NONE, 0};
         Open<R> unused;
-        traverse<R, MODE_CLOSEST>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
+        traverse<R, MODE_CLOSEST, TREE>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
         bool spawned = false;
         if (h.leaf != NONE) {
             Comps<R> c;
@@ -852,7 +859,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             V3<R> surface = mk<R>(0, 0, 0);
             for (uint32_t li = 0; li < sc.n_lights; ++li) { // materials.rs:386-397
                 Incoming<R> in = incoming_at(sc.lights[li], over_point, rng);
-                bool in_shadow = is_shadowed(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
+                bool in_shadow = is_shadowed<R, TREE>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
                 st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
             }
@@ -862,7 +869,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             bool want_n = first_comps && first;
             bool do_refl = !(m.reflective == (R)0) && remaining > 0;   // materials.rs:297
             bool do_refr = !(m.transparency == (R)0) && remaining > 0; // materials.rs:316
-            if (do_refr || want_n) collect_n1n2(sc, ray, origin_leaf, origin_side, h, c, st);
+            if (do_refr || want_n) collect_n1n2<R, TREE>(sc, ray, origin_leaf, origin_side, h, c, st);
             if (first) {
                 if (first_hit) *first_hit = h;
                 if (first_comps) *first_comps = c;
@@ -877,7 +884,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
             Ray<R> refr_ray = ray;
             st.flops += (do_refl ? F_WEIGHT : 0u) + (do_refr ? F_WEIGHT + F_REFRACT_DIR : 0u);
             if (do_refr) { // materials.rs:319-326
-                R n_ratio = c.n1 / c.n2;
+                R n_ratio = div_(c.n1, c.n2);
                 R cos_i = dot(c.eyev, c.normalv);
                 R sin2_t = n_ratio * n_ratio * ((R)1 - cos_i * cos_i);
                 if (sin2_t > (R)1) {
