@@ -53,6 +53,18 @@ def v3(x):
     return np.ascontiguousarray(x, dtype=np.float64)
 
 
+class _Args:
+    """Keeps temporaries alive for the duration of one foreign call: p = _Args(); f(p(origin), p(direction))."""
+
+    def __init__(self):
+        self.keep = []
+
+    def __call__(self, x, dtype=np.float64):
+        a = np.ascontiguousarray(x, dtype=dtype)
+        self.keep.append(a)
+        return a.ctypes.data
+
+
 def render(world, camera, opts=None, n_threads=8, flags=0, row_stride=1, row_offset=0):
     """Camera::render on the oracle: (float64 [v,h,3], stats dict)."""
     from raytracing_amd.abi import STAT_NAMES
@@ -75,48 +87,53 @@ def to_u8(img):
 
 def color_at(flat, origin, direction, remaining, flags=0):
     rgb = np.zeros(3)
-    hit = lib().orc_color_at(flat.desc_address(), v3(origin).ctypes.data, v3(direction).ctypes.data, remaining, flags, rgb.ctypes.data)
+    p = _Args()
+    hit = lib().orc_color_at(flat.desc_address(), p(origin), p(direction), remaining, flags, rgb.ctypes.data)
     return bool(hit), rgb
 
 
 def hit_record(flat, origin, direction, flags=0):
     rec = HitRecord()
-    lib().orc_hit_record(flat.desc_address(), v3(origin).ctypes.data, v3(direction).ctypes.data, flags, C.byref(rec))
+    p = _Args()
+    lib().orc_hit_record(flat.desc_address(), p(origin), p(direction), flags, C.byref(rec))
     return rec
 
 
 def world_intersect(flat, origin, direction, shadow_only=False, cap=64):
     ts = np.zeros(cap)
     leaves = np.zeros(cap, dtype=np.int32)
-    n = lib().orc_world_intersect(flat.desc_address(), v3(origin).ctypes.data, v3(direction).ctypes.data, int(shadow_only), cap,
-                                  ts.ctypes.data, leaves.ctypes.data)
+    p = _Args()
+    n = lib().orc_world_intersect(flat.desc_address(), p(origin), p(direction), int(shadow_only), cap, ts.ctypes.data, leaves.ctypes.data)
     return ts[:min(n, cap)], leaves[:min(n, cap)]
 
 
 def node_intersect(flat, node, origin, direction, cap=64):
     ts = np.zeros(cap)
     leaves = np.zeros(cap, dtype=np.int32)
-    n = lib().orc_node_intersect(flat.desc_address(), node, v3(origin).ctypes.data, v3(direction).ctypes.data, cap, ts.ctypes.data,
-                                 leaves.ctypes.data)
+    p = _Args()
+    n = lib().orc_node_intersect(flat.desc_address(), node, p(origin), p(direction), cap, ts.ctypes.data, leaves.ctypes.data)
     return ts[:min(n, cap)], leaves[:min(n, cap)]
 
 
 def local_intersect(flat, leaf, origin, direction):
     ts = np.zeros(4)
     uv = np.zeros(2)
-    n = lib().orc_local_intersect(flat.leaf_address(leaf), v3(origin).ctypes.data, v3(direction).ctypes.data, ts.ctypes.data, uv.ctypes.data)
+    p = _Args()
+    n = lib().orc_local_intersect(flat.leaf_address(leaf), p(origin), p(direction), ts.ctypes.data, uv.ctypes.data)
     return ts[:n], uv
 
 
 def local_normal(flat, leaf, point, u=0.0, v=0.0):
     n = np.zeros(3)
-    lib().orc_local_normal(flat.leaf_address(leaf), v3(point).ctypes.data, u, v, n.ctypes.data)
+    p = _Args()
+    lib().orc_local_normal(flat.leaf_address(leaf), p(point), u, v, n.ctypes.data)
     return n
 
 
 def normal_at(flat, leaf, point, u=0.0, v=0.0):
     n = np.zeros(3)
-    lib().orc_normal_at(flat.leaf_address(leaf), v3(point).ctypes.data, u, v, n.ctypes.data)
+    p = _Args()
+    lib().orc_normal_at(flat.leaf_address(leaf), p(point), u, v, n.ctypes.data)
     return n
 
 
@@ -127,7 +144,8 @@ def shade_explicit(flat, origin, direction, xs, hit, remaining, what=0, flags=0,
     uv = None if uvs is None else v3(uvs)
     rgb = np.zeros(3)
     rec = HitRecord()
-    ok = lib().orc_shade_explicit(flat.desc_address(), v3(origin).ctypes.data, v3(direction).ctypes.data, len(xs), ts.ctypes.data,
+    p = _Args()
+    ok = lib().orc_shade_explicit(flat.desc_address(), p(origin), p(direction), len(xs), ts.ctypes.data,
                                   leaves.ctypes.data, uv.ctypes.data if uv is not None else None, float(hit[0]), int(hit[1]), remaining,
                                   what, flags, rgb.ctypes.data, C.byref(rec))
     assert ok, "hit not found in intersections"
