@@ -1,7 +1,7 @@
 // rtmi.hip — C ABI (include/rtmi.h) of the MI355X ray-casting core: scene layout + upload, kernels, launches.
 // gfx950 only.  No CPU fallback: without a usable HIP device every compute entry point fails with
 // RTMI_ERR_DEVICE and a message.
-#include "rtmi_device.hpp"
+#include "rtmi_launch.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -10,10 +10,6 @@
 #include <vector>
 
 using namespace rtmi_dev;
-
-#ifndef RTMI_WAVES
-#define RTMI_WAVES 3 // minimum waves per SIMD the render kernels are register-allocated for
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -29,218 +25,8 @@ extern "C" const char *rtmi_last_error(void) { return g_err.c_str(); }
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// kernels
+// kernels: rtmi_kernels.hip (built once per arithmetic type); only the type-free tone map lives here
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *stats) {
-    if (!stats) return;
-#pragma unroll
-    for (int i = 0; i < RTMI_N_STATS; ++i) {
-        if (i == RTMI_STAT_FLOPS) continue;
-        uint32_t s = wave_sum(st.c[i]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
-    }
-    unsigned long long f = st.flops;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
-    if ((threadIdx.x & 63) == 0 && f) atomicAdd(&stats[RTMI_STAT_FLOPS], f);
-}
-
-// Camera::multisample's loop condition (camera.rs:281,290-291 with color_variance_of_mean, 305-310):
-// true while the pixel that has taken `cnt` samples (n == cnt as a float) must take another one.
-template <typename R> __device__ __forceinline__ bool need_more(const DCamera<double> &cam, V3<R> sum, V3<R> sos, R n, uint32_t cnt) {
-    if (cnt == 0) return true;
-    if (cam.max_samples > 0 && cnt >= (uint32_t)cam.max_samples) return false;
-    if (n < (R)cam.min_samples) return true;
-    R inv_n = rcp_(n);
-    V3<R> mean = sum * inv_n;
-    V3<R> var = sos * inv_n - had(mean, mean);
-    R variance = div_(var.x + var.y + var.z, (R)3);
-    return div_(variance, n) > (R)cam.se2;
-}
-
-template <typename R> __device__ __forceinline__ V3<R> shfl3(V3<R> v, int src) {
-    return {__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)};
-}
-
-__device__ __forceinline__ void stats_zero(Stats &s) {
-#pragma unroll
-    for (int i = 0; i < RTMI_N_STATS; ++i) s.c[i] = 0;
-    s.flops = 0;
-}
-__device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
-#pragma unroll
-    for (int i = 0; i < RTMI_N_STATS; ++i) a.c[i] += b.c[i];
-    a.flops += b.flops;
-}
-
-// Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310): one wave64 per 8x8 pixel tile,
-// waves stride over the tiles this rank owns.
-//
-// Adaptive multisampling without the divergence of "one lane loops until its pixel converges": every round the
-// wave counts the pixels of its tile that still need samples (u).  While u > 32 each such pixel's own lane takes
-// its next sample.  Once u <= 32 the 64 lanes are dealt out evenly, G = 64 / pow2ceil(u) lanes per unconverged
-// pixel, and compute that pixel's next G samples (counter RNG: sample s of a pixel is independent of who computes
-// it); a prefix sum over the group in sample order then finds the first sample count at which the reference's
-// loop would have stopped, and samples past it are discarded - their rays are not counted either.
-template <typename R, bool TREE>
-__global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
-                                                    unsigned long long *stats) {
-    Stats st;
-    stats_zero(st);
-    Rng rng;
-    rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
-    const int lane = threadIdx.x & 63;
-    const int sub = rp.tile_rows >> 3; // 8-row rows per ownership tile
-    for (int tile = blockIdx.x; tile < rp.n_tiles; tile += gridDim.x) {
-        int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
-        int lt = ltr / sub, within = ltr - lt * sub;
-        int gt = lt * rp.nranks + rp.rank;
-        const int x0 = tx * 8, y0 = (gt * sub + within) * 8;
-        const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
-        const int ly = ltr * 8 + (lane >> 3);
-        const bool valid = x < cam.hsize && y < cam.vsize;
-        V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
-        R n = 0;
-        uint32_t cnt = 0;
-        for (;;) {
-            const bool act = valid && need_more(cam, sum, sos, n, cnt);
-            const unsigned long long mask = __ballot(act);
-            if (mask == 0) break;
-            const int u = __popcll(mask);
-            // lanes per pixel this round
-            int p2 = 64;
-            if (u <= 32) { p2 = 1; while (p2 < u) p2 <<= 1; }
-            const int G = 64 / p2;
-            const int r = lane / G, j = lane & (G - 1);
-            int owner = act ? lane : -1;
-            if (G > 1) { // the r-th unconverged pixel of the tile belongs to group r
-                owner = -1;
-                unsigned long long m = mask;
-                for (int i = 0; i < p2 && m; ++i) {
-                    int o = __ffsll((long long)m) - 1;
-                    if (i == r) owner = o;
-                    m &= m - 1;
-                }
-            }
-            const bool has = owner >= 0;
-            const int src = has ? owner : lane;
-            const R n0 = __shfl(n, src, 64);
-            const uint32_t cnt0 = __shfl(cnt, src, 64);
-            const V3<R> sum0 = shfl3(sum, src), sos0 = shfl3(sos, src);
-            const uint32_t s = cnt0 + (uint32_t)j;
-            V3<R> c = mk<R>(0, 0, 0);
-            Stats ls;
-            stats_zero(ls);
-            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) {
-                const int ox = x0 + (src & 7), oy = y0 + (src >> 3);
-                rng_begin(rng, (uint32_t)(oy * cam.hsize + ox), s);
-                ls.c[RTMI_STAT_SAMPLES] = 1;
-                ls.flops = camera_flops(cam);
-                Ray<R> ray = camera_ray<R>(cam, ox, oy, s != 0, rng);
-                c = color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, ls, nullptr, nullptr);
-            }
-            // inclusive prefix sums over the group, in sample order
-            V3<R> ps = c, pq = had(c, c);
-            for (int off = 1; off < G; off <<= 1) {
-                V3<R> a = {__shfl_up(ps.x, off, G), __shfl_up(ps.y, off, G), __shfl_up(ps.z, off, G)};
-                V3<R> b = {__shfl_up(pq.x, off, G), __shfl_up(pq.y, off, G), __shfl_up(pq.z, off, G)};
-                if (j >= off) { ps = ps + a; pq = pq + b; }
-            }
-            const V3<R> sj = sum0 + ps, qj = sos0 + pq;
-            const R nj = n0 + (R)(j + 1);
-            const uint32_t cntj = cnt0 + (uint32_t)j + 1u;
-            const bool stop = has && !need_more(cam, sj, qj, nj, cntj);
-            const unsigned long long sb = __ballot(stop);
-            const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-            const unsigned long long gb = (sb >> (r * G)) & gmask;
-            const int k_used = gb ? __ffsll((long long)gb) : G; // samples of this group that the reference would have taken
-            if (has && j < k_used) stats_add(st, ls);
-            // hand the result back to the pixel's own lane
-            const int rk = G > 1 ? __popcll(mask & ((1ull << lane) - 1ull)) : lane;
-            const int gbase = act ? rk * G : lane;
-            const int kk = __shfl(k_used, gbase, 64);
-            const int fin = act ? gbase + kk - 1 : lane;
-            const V3<R> fs = shfl3(sj, fin), fq = shfl3(qj, fin);
-            const R fn = __shfl(nj, fin, 64);
-            if (act) { sum = fs; sos = fq; n = fn; cnt += (uint32_t)kk; }
-        }
-        if (valid) {
-            R inv_n = (R)1 / n;
-            size_t o = ((size_t)ly * cam.hsize + x) * 3;
-            out[o + 0] = (float)(sum.x * inv_n);
-            out[o + 1] = (float)(sum.y * inv_n);
-            out[o + 2] = (float)(sum.z * inv_n);
-        }
-    }
-    flush_stats(st, stats);
-}
-
-// World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays)
-template <typename R>
-__global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
-                                                   const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Stats st;
-#pragma unroll
-    for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
-    st.flops = 0;
-    Rng rng;
-    rng.k0 = seed_lo; rng.k1 = seed_hi;
-    rng_begin(rng, (uint32_t)i, 0);
-    Ray<R> ray = {mk<R>((R)origins[3 * i], (R)origins[3 * i + 1], (R)origins[3 * i + 2]),
-                  mk<R>((R)dirs[3 * i], (R)dirs[3 * i + 1], (R)dirs[3 * i + 2])};
-    Hit<R> h;
-    Comps<R> c;
-    c.point = mk<R>(0, 0, 0); c.normalv = c.point; c.eyev = c.point; c.inside = false; c.side_plus = false; c.n1 = 1; c.n2 = 1;
-    int rem = remaining ? remaining[i] : (int)sc.max_depth;
-    V3<R> col = color_at<R, true>(sc, ray, rem, rng, st, &h, &c);
-    if (rgb) { rgb[3 * i] = (double)col.x; rgb[3 * i + 1] = (double)col.y; rgb[3 * i + 2] = (double)col.z; }
-    if (recs) {
-        rtmi_hit_record r;
-        memset(&r, 0, sizeof r);
-        r.shadowed = -1.0;
-        if (h.leaf != NONE) {
-            r.hit = 1;
-            r.leaf = (int32_t)sc.leaf_orig[h.leaf];
-            r.inside = c.inside ? 1 : 0;
-            r.t = (double)h.t;
-            r.point[0] = (double)c.point.x; r.point[1] = (double)c.point.y; r.point[2] = (double)c.point.z;
-            r.normal[0] = (double)c.normalv.x; r.normal[1] = (double)c.normalv.y; r.normal[2] = (double)c.normalv.z;
-            r.n1 = (double)c.n1; r.n2 = (double)c.n2;
-            if (sc.n_lights > 0) {
-                int k = sc.lights[0].kind;
-                if (k == RTMI_LIGHT_POINT || k == RTMI_LIGHT_REALISTIC_POINT || k == RTMI_LIGHT_BEAM) {
-                    V3<R> over_point = c.point + c.normalv * (R)RTMI_EPSILON;
-                    Incoming<R> in = incoming_at(sc.lights[0], over_point, rng);
-                    if (in.kind == IL_RAY) r.shadowed = is_shadowed<R, true>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st) ? 1.0 : 0.0;
-                }
-            }
-        }
-        recs[i] = r;
-    }
-}
-
-// Camera::ray_for_pixel for a batch of (px, py, sample) (rtmi_camera_rays)
-template <typename R>
-__global__ void camera_rays_kernel(DCamera<double> cam, uint32_t seed_lo, uint32_t seed_hi, long long n, const int *px, const int *py,
-                                   const int *sample, double *origins, double *dirs) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Rng rng;
-    rng.k0 = seed_lo; rng.k1 = seed_hi;
-    int s = sample ? sample[i] : 0;
-    rng_begin(rng, (uint32_t)(py[i] * cam.hsize + px[i]), (uint32_t)s);
-    Ray<R> r = camera_ray<R>(cam, px[i], py[i], s != 0, rng);
-    origins[3 * i] = (double)r.o.x; origins[3 * i + 1] = (double)r.o.y; origins[3 * i + 2] = (double)r.o.z;
-    dirs[3 * i] = (double)r.d.x; dirs[3 * i + 1] = (double)r.d.y; dirs[3 * i + 2] = (double)r.d.z;
-}
 
 // Color::to_u8 (color.rs:53-60): clip, x255, round half away from zero.  4 values per lane.
 __global__ void tonemap_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, long long n) {
@@ -644,13 +430,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     const bool tree = s->h32.root_child_count != 0;
     DCamera<double> cam = make_camera<double>(c, o);
     unsigned long long *ds = (unsigned long long *)d_stats;
-    if (f64) {
-        if (tree) hipLaunchKernelGGL((render_kernel<double, true>), dim3(grid), dim3(64), 0, st, s->h64, cam, rp, d_out, ds);
-        else hipLaunchKernelGGL((render_kernel<double, false>), dim3(grid), dim3(64), 0, st, s->h64, cam, rp, d_out, ds);
-    } else {
-        if (tree) hipLaunchKernelGGL((render_kernel<float, true>), dim3(grid), dim3(64), 0, st, s->h32, cam, rp, d_out, ds);
-        else hipLaunchKernelGGL((render_kernel<float, false>), dim3(grid), dim3(64), 0, st, s->h32, cam, rp, d_out, ds);
-    }
+    if (f64) launch_render_kernel<double>(tree, grid, st, s->h64, cam, rp, d_out, ds);
+    else launch_render_kernel<float>(tree, grid, st, s->h32, cam, rp, d_out, ds);
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }
@@ -736,8 +517,8 @@ extern "C" int rtmi_trace_rays(const rtmi_scene *scene, const rtmi_render_opts *
     uint64_t seed = opts ? opts->seed : 0;
     bool f64 = opts && opts->precision == RTMI_PRECISION_F64;
     int grid = (int)((n + 63) / 64);
-    if (f64) hipLaunchKernelGGL(trace_kernel<double>, dim3(grid), dim3(64), 0, 0, scene->h64, (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_o, d_d, d_rem, d_rgb, d_rec);
-    else hipLaunchKernelGGL(trace_kernel<float>, dim3(grid), dim3(64), 0, 0, scene->h32, (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_o, d_d, d_rem, d_rgb, d_rec);
+    if (f64) launch_trace_kernel<double>(grid, scene->h64, (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_o, d_d, d_rem, d_rgb, d_rec);
+    else launch_trace_kernel<float>(grid, scene->h32, (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_o, d_d, d_rem, d_rgb, d_rec);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipDeviceSynchronize());
     if (rgb_out) TRY_OR_CLEAN(hipMemcpy(rgb_out, d_rgb, b3, hipMemcpyDeviceToHost));
@@ -771,8 +552,8 @@ extern "C" int rtmi_camera_rays(const rtmi_camera *camera, const rtmi_render_opt
     uint64_t seed = opts ? opts->seed : 0;
     bool f64 = opts && opts->precision == RTMI_PRECISION_F64;
     int grid = (int)((n + 255) / 256);
-    if (f64) hipLaunchKernelGGL(camera_rays_kernel<double>, dim3(grid), dim3(256), 0, 0, make_camera<double>(camera, opts), (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_px, d_py, d_s, d_o, d_d);
-    else hipLaunchKernelGGL(camera_rays_kernel<float>, dim3(grid), dim3(256), 0, 0, make_camera<double>(camera, opts), (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_px, d_py, d_s, d_o, d_d);
+    if (f64) launch_camera_rays_kernel<double>(grid, make_camera<double>(camera, opts), (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_px, d_py, d_s, d_o, d_d);
+    else launch_camera_rays_kernel<float>(grid, make_camera<double>(camera, opts), (uint32_t)seed, (uint32_t)(seed >> 32), (long long)n, d_px, d_py, d_s, d_o, d_d);
     TRY_OR_CLEAN(hipGetLastError());
     TRY_OR_CLEAN(hipDeviceSynchronize());
     TRY_OR_CLEAN(hipMemcpy(origins_out, d_o, b3, hipMemcpyDeviceToHost));
