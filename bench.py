@@ -8,7 +8,8 @@ Workload (BASELINE.json configs[1]): the reference's chapter-11a reflection/refr
     python bench.py --gpus N --steps K --warmup W            (N > 1: one process per GPU under torch.distributed.run)
 
 N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
-gathers the rows to rank 0 with RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py); the render runs on its own
+HIP stream, double-buffered, so frame i+1 renders while frame i is gathered.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -100,23 +101,32 @@ def main():
     prec = 0 if a.precision == "f32" else 1
     opts = abi.make_opts(seed=a.seed, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
     h, v = cam.hsize(), cam.vsize()
-    my_rows = abi.rank_rows(v, rank, world_size, a.tile_rows)
-    max_rows = max(abi.rank_rows(v, r, world_size, a.tile_rows) for r in range(world_size))
-    local = torch.zeros((max_rows, h, 3), dtype=torch.float32, device=dev)
+    from raytracing_amd import tiles
+    gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=dev)
+    assert gather.rows == abi.rank_rows(v, rank, world_size, a.tile_rows)
+    bufs = [gather.new_local(), gather.new_local()]  # double-buffered: frame i+1 renders while frame i is gathered
     stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros_like(local) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
-    stream = torch.cuda.current_stream().cuda_stream
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    render_stream = torch.cuda.Stream(device=dev)
+    ev_rendered = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+    frames = {"n": 0, "last": None}
 
     def step(timed_events=None):
-        if timed_events is not None:
-            timed_events[0].record()
-        abi.render_device(scene, cam, opts, local, stats, stream)
-        if timed_events is not None:
-            timed_events[1].record()
-        if world_size > 1:
-            dist.gather(local, gathered, dst=0)
+        """One frame: render this rank's row tiles (own stream), then gather the rows to rank 0 and assemble the canvas."""
+        b = frames["n"] & 1
+        frames["n"] += 1
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(render_stream):
+            render_stream.wait_event(ev_free[b])
+            if timed_events is not None:
+                timed_events[0].record(render_stream)
+            abi.render_device(scene, cam, opts, bufs[b], stats, render_stream.cuda_stream)
+            if timed_events is not None:
+                timed_events[1].record(render_stream)
+            ev_rendered[b].record(render_stream)
+        cur.wait_event(ev_rendered[b])
+        frames["last"] = gather.gather(bufs[b])
+        ev_free[b].record(cur)
 
     def barrier():
         if world_size > 1:
@@ -127,7 +137,6 @@ def main():
         step()
     barrier()
     stats.zero_()
-    kernel_ms = []
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     barrier()
     t0 = time.perf_counter()

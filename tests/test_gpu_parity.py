@@ -129,11 +129,7 @@ def test_row_tile_sharding_is_bit_identical():
         stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device="cuda")
         abi.render_device(sc, cam, abi.make_opts(rank=r, nranks=nr, tile_rows=tr), buf, stats, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        loc = buf.cpu().numpy()
-        k = 0
-        for t in range(r, (v + tr - 1) // tr, nr):
-            n = min(tr, v - t * tr)
-            out[t * tr:t * tr + n] = loc[k:k + n]
-            k += n
+        from raytracing_amd import tiles
+        out[tiles.rank_row_index(v, r, nr, tr).numpy()] = buf.cpu().numpy()  # the row map the RCCL gather uses
     sc.close()
     assert np.array_equal(out, full)
