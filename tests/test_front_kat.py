@@ -264,3 +264,19 @@ def test_scene_validation_errors_are_loud():
     w.set_max_reflection_depth(99)
     with pytest.raises(abi.RtmiError, match="max_depth"):
         abi.Scene(w)
+
+
+def test_cpp_example_compiles_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/render_ppm.cpp (the C++ front end of INTEGRATION.md section 5) builds against include/ + librtmi.so; on a
+    machine without a GPU it must exit non-zero with the library's message instead of producing an image."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "render_ppm")
+    libdir = os.path.join(root, "raytracing_amd")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "render_ppm.cpp"),
+                    "-L" + libdir, "-lrtmi", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the example is run by the gpu tests")
+    r = subprocess.run([exe, str(tmp_path / "o.ppm"), "32"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU path" in r.stderr
