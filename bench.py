@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--max-samples", type=int, default=0, help="cap on samples per pixel (0 = unbounded like the reference; diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
     return ap.parse_args()
@@ -46,6 +47,8 @@ def workload_name(a):
              "ch11b": "chapter-11b water reflection/refraction, depth 5", "teapot": "chapter-15 teapot mesh in host-built BVH",
              "soft": "soft_shadow sphere light", "dof": "depth-of-field thin lens", "dice": "chapter-16 CSG dice + lens"}
     samp = "adaptive multisampling as shipped" if a.sampling == "shipped" else "1 centred sample per pixel"
+    if a.max_samples:
+        samp += " capped at %d samples/pixel" % a.max_samples
     return "%s, %dx%d, %s" % (names[a.scene], a.width, a.height, samp)
 
 
@@ -56,7 +59,7 @@ def cpu_baseline(world, cam, a, scenes):
     import oracle_lib as orc
     from raytracing_amd import abi
     threads = min(os.cpu_count() or 1, 16)
-    opts = abi.make_opts(seed=a.seed)
+    opts = abi.make_opts(seed=a.seed, max_samples=a.max_samples)
     rays = lambda st: st["primary"] + st["reflection"] + st["refraction"] + st["shadow"]
     v = cam.vsize()
     stride = max(1, v // 16)  # probe: ~16 rows
@@ -99,7 +102,7 @@ def main():
     world, cam = build(a.width, a.height, deterministic=(a.sampling == "1spp"))
     scene = abi.Scene(world)
     prec = 0 if a.precision == "f32" else 1
-    opts = abi.make_opts(seed=a.seed, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
+    opts = abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
     h, v = cam.hsize(), cam.vsize()
     from raytracing_amd import tiles
     gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=dev)
@@ -185,6 +188,7 @@ def main():
             "config": {"workload": workload_name(a), "scene": a.scene, "max_depth": int(world.max_reflection_depth),
                        "seed": a.seed, "sharding": "8-row tiles round-robin, RCCL gather to rank 0" if world_size > 1 else "none",
                        "rays_per_step": rays // a.steps, "samples_per_step": S["samples"] // a.steps,
+                       "discarded_samples_per_step": S["discarded"] // a.steps,
                        "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,

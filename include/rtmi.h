@@ -188,7 +188,9 @@ enum {
     RTMI_STAT_FLOPS = 8,      /* algorithmic FLOPs of the events above, priced with the constants
                                  of DESIGN.md "FLOP accounting"                         */
     RTMI_STAT_AABB_TESTS = 9, /* slab tests                                                        */
-    RTMI_N_STATS = 10
+    RTMI_STAT_DISCARDED = 10, /* samples computed ahead of the stopping rule and thrown away (never
+                                 counted in any of the above; the oracle reports 0)                 */
+    RTMI_N_STATS = 11
 };
 
 typedef struct rtmi_stats {

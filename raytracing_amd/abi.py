@@ -8,8 +8,8 @@ import os
 
 from . import LIB_PATH
 
-N_STATS = 10
-STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_tests", "node_visits", "overflow", "flops", "aabb_tests")
+N_STATS = 11
+STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_tests", "node_visits", "overflow", "flops", "aabb_tests", "discarded")
 
 # every symbol include/rtmi.h declares
 SYMBOLS = (

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -54,8 +55,62 @@ template <typename R> struct DeviceArrays {
     DLight<R> *lights = nullptr;
 };
 
+// Work-queue memory of the adaptive second pass (rtmi_launch.hpp DWork): a per-device pool of WORK_SLOTS buffers,
+// created with the first scene on the device and freed with the last, so that rendering itself allocates nothing.
+// A stream is bound to a slot the first time it renders; work on one stream is ordered, so one slot per stream is
+// race-free, and renders on different streams use different slots.
+constexpr int WORK_SLOTS = 8;
+constexpr size_t WORK_BYTES = 32u << 20;
+constexpr int MAX_DEVICES = 64;
+struct WorkPool {
+    int refs = 0;
+    void *buf[WORK_SLOTS] = {};
+    hipStream_t stream[WORK_SLOTS] = {};
+    bool used[WORK_SLOTS] = {};
+};
+static std::mutex g_pool_mutex;
+static WorkPool g_pool[MAX_DEVICES];
+
+static int pool_acquire(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(RTMI_ERR_UNSUPPORTED, "device ordinal beyond 63");
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    WorkPool &p = g_pool[dev];
+    if (p.refs == 0) {
+        for (int i = 0; i < WORK_SLOTS; ++i) {
+            hipError_t e = hipMalloc(&p.buf[i], WORK_BYTES);
+            if (e != hipSuccess) {
+                for (int k = 0; k < i; ++k) { (void)hipFree(p.buf[k]); p.buf[k] = nullptr; }
+                p.buf[i] = nullptr;
+                return fail(RTMI_ERR_NOMEM, std::string("work-queue pool: ") + hipGetErrorString(e));
+            }
+            p.used[i] = false;
+        }
+    }
+    ++p.refs;
+    return RTMI_OK;
+}
+
+static void pool_release(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    WorkPool &p = g_pool[dev];
+    if (p.refs > 0 && --p.refs == 0)
+        for (int i = 0; i < WORK_SLOTS; ++i) { (void)hipFree(p.buf[i]); p.buf[i] = nullptr; p.used[i] = false; }
+}
+
+// the slot bound to `st` (binding it if this stream is new); nullptr when all slots belong to other streams
+static void *pool_slot(int dev, hipStream_t st) {
+    WorkPool &p = g_pool[dev];
+    for (int i = 0; i < WORK_SLOTS; ++i)
+        if (p.used[i] && p.stream[i] == st) return p.buf[i];
+    for (int i = 0; i < WORK_SLOTS; ++i)
+        if (!p.used[i]) { p.used[i] = true; p.stream[i] = st; return p.buf[i]; }
+    return nullptr;
+}
+
 struct rtmi_scene {
     int device = -1;
+    bool pooled = false;
     DeviceArrays<float> f32;
     DeviceArrays<double> f64;
     DNode *nodes = nullptr;
@@ -236,6 +291,23 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
         g.material = (uint32_t)s.material;
         g.csg_parent = L.leaf_csg[i];
         g.tri = 0;
+        if (sizeof(R) == 4 && s.kind == RTMI_SPHERE) {
+            // similarity test on the world->object matrix M (rows of inv): M^T M = k I  =>  radius^2 = 1/k and the
+            // world centre is -M^-1 t = -(1/k) M^T t
+            const double *m = s.inv;
+            double k = m[0] * m[0] + m[4] * m[4] + m[8] * m[8];
+            bool sim = k > 0 && std::isfinite(k) && m[12] == 0 && m[13] == 0 && m[14] == 0 && m[15] == 1;
+            for (int a = 0; a < 3 && sim; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double e = m[a] * m[b] + m[4 + a] * m[4 + b] + m[8 + a] * m[8 + b] - (a == b ? k : 0.0);
+                    if (std::fabs(e) > 1e-12 * k) sim = false;
+                }
+            if (sim) {
+                for (int a = 0; a < 3; ++a) g.fast[a] = (R)(-(m[a] * m[3] + m[4 + a] * m[7] + m[8 + a] * m[11]) / k);
+                g.fast[3] = (R)(1.0 / k);
+                g.kind |= LEAF_FAST;
+            }
+        }
         if (s.kind == RTMI_TRIANGLE || s.kind == RTMI_SMOOTH_TRIANGLE) {
             DTri<R> t;
             double e1[3], e2[3];
@@ -345,6 +417,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
     (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig);
+    if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
 }
@@ -368,6 +441,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32);
     if (rc == RTMI_OK) rc = upload_typed<double>(desc, L, s->f64);
+    if (rc == RTMI_OK && (rc = pool_acquire(dev)) == RTMI_OK) s->pooled = true;
     if (rc != RTMI_OK) { rtmi_scene_destroy(s); return rc; }
     header(s, desc, L, s->f32, s->h32);
     header(s, desc, L, s->f64, s->h64);
@@ -409,6 +483,10 @@ static int check_camera(const rtmi_camera *c) {
     return RTMI_OK;
 }
 
+#ifndef RTMI_RESAMPLE_WAVES
+#define RTMI_RESAMPLE_WAVES 3 // waves per SIMD of the second pass's persistent grid
+#endif
+
 static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st) {
     int rank = 0, nranks = 1, tr = 8;
     if (o && o->nranks > 1) {
@@ -430,8 +508,19 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     const bool tree = s->h32.root_child_count != 0;
     DCamera<double> cam = make_camera<double>(c, o);
     unsigned long long *ds = (unsigned long long *)d_stats;
-    if (f64) launch_render_kernel<double>(tree, grid, st, s->h64, cam, rp, d_out, ds);
-    else launch_render_kernel<float>(tree, grid, st, s->h32, cam, rp, d_out, ds);
+    // the open-ended part of Camera::multisample runs as a second kernel over work queues (only if it can be reached)
+    const bool open_ended = std::isfinite(c->allowed_standard_error) && !(cam.max_samples > 0 && cam.max_samples <= cam.min_samples);
+    void *work = nullptr;
+    std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
+    if (open_ended) {
+        lock.lock(); // held until both kernels are enqueued: calls sharing a stream must not interleave their launches
+        work = pool_slot(s->device, st);
+        if (!work) return fail(RTMI_ERR_UNSUPPORTED, "more than 8 streams are rendering on this device (one work-queue slot per stream)");
+        HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st));
+    }
+    const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
+    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, WORK_BYTES);
+    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, WORK_BYTES);
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }

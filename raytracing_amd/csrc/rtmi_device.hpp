@@ -42,6 +42,7 @@ constexpr int CSG_MAX_NODES = 32;  // CSG operator nodes under one root (2 state
 constexpr uint32_t LEAF_KIND_MASK = 0xFFu;
 constexpr uint32_t LEAF_CLOSED = 1u << 8;
 constexpr uint32_t LEAF_CAST_SHADOW = 1u << 9;
+constexpr uint32_t LEAF_FAST = 1u << 10; // f32 only: sphere under a similarity transform, tested in world space (fast[])
 
 // node.flags
 constexpr uint32_t NODE_CSGROOT = 1u << 0;
@@ -51,11 +52,11 @@ constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
 template <typename R> struct DLeaf {
     R inv[12];           // rows 0..2 of the world->object matrix
     R minimum, maximum;  // cylinder / cone
-    uint32_t kind;       // kind | LEAF_CLOSED | LEAF_CAST_SHADOW
+    R fast[4];           // LEAF_FAST: world-space centre and squared radius
+    uint32_t kind;       // kind | LEAF_CLOSED | LEAF_CAST_SHADOW | LEAF_FAST
     uint32_t material;
     uint32_t tri;        // index into tris (triangle kinds)
     uint32_t csg_parent; // innermost enclosing CSG operator, or NONE
-    uint32_t pad[2];
 };
 
 template <typename R> struct DTri {
@@ -407,10 +408,34 @@ constexpr uint32_t SIDE_PLUS = 1u; // smooth triangles: the spawn point lies on 
 template <typename R>
 __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, uint32_t origin_side,
                                           R t[4], R &u, R &v, Stats &st) {
-    V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
+    const uint32_t kind = g.kind & LEAF_KIND_MASK;
     uint32_t fl;
     R det = 0;
-    int n = local_intersect(g, tris, o, d, t, u, v, fl, det);
+    int n = 0;
+    if (sizeof(R) == 4 && (g.kind & LEAF_FAST)) {
+        // f32 product path: a sphere whose transform is a similarity is the world-space sphere |p - c|^2 = r^2; the
+        // ray parameter t is the same in both spaces (ray.rs:30-35 does not renormalise), so these are the roots of
+        // sphere.rs:47-63 at a third of the arithmetic.  Roots as closest approach -+ half chord (no cancellation).
+        const V3<R> oc = ray.o - ld3(g.fast);
+        const R a = dot(ray.d, ray.d), inv_a = rcp_(a), hb = dot(ray.d, oc);
+        const V3<R> l = oc - ray.d * (hb * inv_a);
+        const R disc4 = a * (g.fast[3] - dot(l, l));
+        fl = F_SPHERE_MISS;
+        if (!(disc4 < (R)0)) {
+            const R tm = -hb * inv_a, hc = sqrt_(disc4) * inv_a;
+            t[0] = tm - hc; t[1] = tm + hc;
+            n = 2;
+            fl = F_SPHERE_HIT;
+        }
+    } else if (kind == RTMI_PLANE) { // plane.rs:35-44 needs the y row of the object-space ray only
+        const R oy = g.inv[4] * ray.o.x + g.inv[5] * ray.o.y + g.inv[6] * ray.o.z + g.inv[7];
+        const R dy = g.inv[4] * ray.d.x + g.inv[5] * ray.d.y + g.inv[6] * ray.d.z;
+        fl = F_PLANE;
+        if (!(abs_(dy) < (R)RTMI_EPSILON)) { t[0] = div_(-oy, dy); n = 1; }
+    } else {
+        V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
+        n = local_intersect(g, tris, o, d, t, u, v, fl, det);
+    }
     st.c[RTMI_STAT_LEAF_TESTS]++;
     st.flops += F_XFORM + fl;
     if (is_origin && n > 0) {
@@ -776,7 +801,9 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
         u = f * dot(p1_to_origin, dir_cross_e2);
         v = f * dot(d, cross(p1_to_origin, e1));
     }
-    V3<R> n = normalize(xf_normal(g.inv, local_normal(g, sc.tris, obj_point, u, v))); // shapes/mod.rs:261-265,319-322
+    V3<R> n;
+    if (sizeof(R) == 4 && (g.kind & LEAF_FAST)) n = normalize(c.point - ld3(g.fast)); // similarity: inv^T inv (p - c) is parallel to p - c
+    else n = normalize(xf_normal(g.inv, local_normal(g, sc.tris, obj_point, u, v))); // shapes/mod.rs:261-265,319-322
     c.inside = dot(n, c.eyev) < (R)0;
     c.normalv = c.inside ? -n : n;
     c.side_plus = dot(xf_vector(g.inv, c.normalv), ng) > (R)0;

@@ -63,103 +63,181 @@ __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
     a.flops += b.flops;
 }
 
-// Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310): one wave64 per 8x8 pixel tile,
-// waves stride over the tiles this rank owns.
-//
-// Adaptive multisampling without the divergence of "one lane loops until its pixel converges": every round the
-// wave counts the pixels of its tile that still need samples (u).  While u > 32 each such pixel's own lane takes
-// its next sample.  Once u <= 32 the 64 lanes are dealt out evenly, G = 64 / pow2ceil(u) lanes per unconverged
-// pixel, and compute that pixel's next G samples (counter RNG: sample s of a pixel is independent of who computes
-// it); a prefix sum over the group in sample order then finds the first sample count at which the reference's
-// loop would have stopped, and samples past it are discarded - their rays are not counted either.
+// One sample of Camera::multisample's loop body (camera.rs:274-276,283-285,292-296): sample 0 is the centred ray.
+template <typename R, bool TREE>
+__device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<double> &cam, Rng &rng, Stats &st, int px, int py, uint32_t s) {
+    rng_begin(rng, (uint32_t)(py * cam.hsize + px), s);
+    st.c[RTMI_STAT_SAMPLES]++;
+    st.flops += camera_flops(cam);
+    Ray<R> ray = camera_ray<R>(cam, px, py, s != 0, rng);
+    return color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
+}
+
+// Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310), first pass: one wave64 per 8x8 pixel tile,
+// waves stride over the tiles this rank owns; every pixel takes its first min_samples samples on its own lane (all 64
+// lanes busy, neighbouring rays coherent).  Pixels the reference's loop would stop at (camera.rs:290-291) are written
+// out.  The others - a few per cent of the frame, needing anything from one to thousands of further samples - are
+// appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
+// then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
 template <typename R, bool TREE>
 __global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
-                                                    unsigned long long *stats) {
+                                                    unsigned long long *stats, DWork<R> wk) {
     Stats st;
     stats_zero(st);
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
     const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int sub = rp.tile_rows >> 3; // 8-row rows per ownership tile
     for (int tile = blockIdx.x; tile < rp.n_tiles; tile += gridDim.x) {
         int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
         int lt = ltr / sub, within = ltr - lt * sub;
         int gt = lt * rp.nranks + rp.rank;
-        const int x0 = tx * 8, y0 = (gt * sub + within) * 8;
-        const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        const int x = tx * 8 + (lane & 7), y = (gt * sub + within) * 8 + (lane >> 3);
         const int ly = ltr * 8 + (lane >> 3);
         const bool valid = x < cam.hsize && y < cam.vsize;
         V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
-        R n = 0;
         uint32_t cnt = 0;
-        for (;;) {
-            const bool act = valid && need_more(cam, sum, sos, n, cnt);
+        const uint32_t first = cam.max_samples > 0 && cam.max_samples < cam.min_samples ? (uint32_t)cam.max_samples : (uint32_t)cam.min_samples;
+        bool go = valid, queued = false;
+        while (go) { // wave-uniform for the first `first` iterations; afterwards only lanes without a queue slot stay
+            V3<R> c = take_sample<R, TREE>(sc, cam, rng, st, x, y, cnt);
+            sum = sum + c; sos = sos + had(c, c);
+            ++cnt;
+            if (cnt < first) continue;
+            bool more = need_more(cam, sum, sos, (R)cnt, cnt);
+            if (more && cnt == first && wk.hdr) { // decided once per pixel, by all such lanes of the tile together
+                // predicted samples still to take: the loop stops when variance / n <= SE^2
+                const R inv_n = rcp_((R)cnt);
+                const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean);
+                const R want = div_(var.x + var.y + var.z, (R)3 * (R)cam.se2) - (R)cnt;
+                const bool heavy = want > (R)RTMI_LIGHT_NEED;
+                const unsigned long long mh = __ballot(heavy), ml = __ballot(!heavy);
+                const unsigned long long mine = heavy ? mh : ml;
+                const int leader = __ffsll((long long)mine) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&wk.hdr[heavy ? WK_HEAVY_COUNT : WK_LIGHT_COUNT], (uint32_t)__popcll(mine));
+                base = __shfl(base, leader, 64);
+                const uint32_t slot = base + (uint32_t)__popcll(mine & lt_mask);
+                if (slot < wk.cap) {
+                    DWorkItem<R> *q = (heavy ? wk.heavy : wk.light) + slot;
+                    q->px = (uint32_t)x; q->py = (uint32_t)y; q->out_row = (uint32_t)ly; q->cnt = cnt;
+                    q->sum[0] = sum.x; q->sum[1] = sum.y; q->sum[2] = sum.z;
+                    q->sos[0] = sos.x; q->sos[1] = sos.y; q->sos[2] = sos.z;
+                    queued = true;
+                    more = false;
+                } // else: the queue is full and this lane finishes its pixel alone (slow, still exact)
+            }
+            go = more;
+        }
+        if (valid && !queued) {
+            R inv = (R)1 / (R)cnt;
+            size_t o = ((size_t)ly * cam.hsize + x) * 3;
+            out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
+        }
+    }
+    flush_stats(st, stats);
+}
+
+// Camera::multisample's open-ended loop (camera.rs:290-299) for the pixels render_kernel queued.  Waves pop work until
+// both queues are empty: first the heavy queue, one pixel per wave (longest jobs first), then the light queue, eight
+// pixels per wave.  A group of G lanes computes a pixel's next G samples at once (counter RNG: sample s of a pixel
+// does not depend on who computes it); a prefix sum over the group in sample order then finds the first sample count
+// at which the reference's sequential loop would have stopped.  Samples past it are discarded, their rays not counted.
+// Every wave reaches the exit: the pop counters only grow and the queue lengths are fixed before the launch.
+template <typename R, bool TREE>
+__global__ void __launch_bounds__(64, RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+                                                      unsigned long long *stats, DWork<R> wk) {
+    Stats st;
+    stats_zero(st);
+    Rng rng;
+    rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_heavy = min(wk.hdr[WK_HEAVY_COUNT], wk.cap), n_light = min(wk.hdr[WK_LIGHT_COUNT], wk.cap);
+    bool heavy_left = n_heavy > 0;
+    for (;;) {
+        // ---- pop a batch ------------------------------------------------------------------------------------
+        const DWorkItem<R> *items = nullptr;
+        int P = 0;
+        bool heavy_batch = false;
+        if (heavy_left) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&wk.hdr[WK_HEAVY_HEAD], 1u);
+            b = __shfl(b, 0, 64);
+            if (b < n_heavy) { items = wk.heavy + b; P = 1; heavy_batch = true; }
+            else heavy_left = false;
+        }
+        if (!P) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&wk.hdr[WK_LIGHT_HEAD], (uint32_t)RTMI_LIGHT_BATCH);
+            b = __shfl(b, 0, 64);
+            if (b >= n_light) break;
+            items = wk.light + b;
+            P = (int)min((uint32_t)RTMI_LIGHT_BATCH, n_light - b);
+        }
+        const bool valid = lane < P;
+        V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
+        uint32_t cnt = 0;
+        int px = 0, py = 0, out_row = 0;
+        if (valid) {
+            const DWorkItem<R> &q = items[lane];
+            px = (int)q.px; py = (int)q.py; out_row = (int)q.out_row; cnt = q.cnt;
+            sum = mk<R>(q.sum[0], q.sum[1], q.sum[2]);
+            sos = mk<R>(q.sos[0], q.sos[1], q.sos[2]);
+        }
+        // ---- rounds -----------------------------------------------------------------------------------------
+        // The chunking of a pixel's samples depends on that pixel alone (never on its neighbours in the batch or on
+        // the order of the queue), so its sums - and with them the image - are reproducible bit for bit:
+        // heavy pixels take 64 samples per round; light pixels RTMI_LIGHT_ROUNDS rounds of 8, then 64 per round, one
+        // pixel after the other.
+        for (int round = 0;; ++round) {
+            const bool act = valid && need_more(cam, sum, sos, (R)cnt, cnt);
             const unsigned long long mask = __ballot(act);
             if (mask == 0) break;
-            const int u = __popcll(mask);
-            // lanes per pixel this round
-            int p2 = 64;
-            if (u <= 32) { p2 = 1; while (p2 < u) p2 <<= 1; }
-            const int G = 64 / p2;
-            const int r = lane / G, j = lane & (G - 1);
-            int owner = act ? lane : -1;
-            if (G > 1) { // the r-th unconverged pixel of the tile belongs to group r
-                owner = -1;
-                unsigned long long m = mask;
-                for (int i = 0; i < p2 && m; ++i) {
-                    int o = __ffsll((long long)m) - 1;
-                    if (i == r) owner = o;
-                    m &= m - 1;
-                }
-            }
+            const bool wide = heavy_batch || round >= RTMI_LIGHT_ROUNDS;
+            const int G = wide ? 64 : 64 / RTMI_LIGHT_BATCH;
+            const int r = wide ? 0 : lane / G, j = wide ? lane : lane & (G - 1);
+            const int owner = wide ? __ffsll((long long)mask) - 1 : (((mask >> r) & 1ull) ? r : -1);
             const bool has = owner >= 0;
             const int src = has ? owner : lane;
-            const R n0 = __shfl(n, src, 64);
             const uint32_t cnt0 = __shfl(cnt, src, 64);
             const V3<R> sum0 = shfl3(sum, src), sos0 = shfl3(sos, src);
+            const int ox = __shfl(px, src, 64), oy = __shfl(py, src, 64);
             const uint32_t s = cnt0 + (uint32_t)j;
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
             stats_zero(ls);
-            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) {
-                const int ox = x0 + (src & 7), oy = y0 + (src >> 3);
-                rng_begin(rng, (uint32_t)(oy * cam.hsize + ox), s);
-                ls.c[RTMI_STAT_SAMPLES] = 1;
-                ls.flops = camera_flops(cam);
-                Ray<R> ray = camera_ray<R>(cam, ox, oy, s != 0, rng);
-                c = color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, ls, nullptr, nullptr);
-            }
-            // inclusive prefix sums over the group, in sample order
+            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE>(sc, cam, rng, ls, ox, oy, s);
+            // inclusive prefix sums over the group, in sample order (the association depends on j only)
             V3<R> ps = c, pq = had(c, c);
-            for (int off = 1; off < G; off <<= 1) {
-                V3<R> a = {__shfl_up(ps.x, off, G), __shfl_up(ps.y, off, G), __shfl_up(ps.z, off, G)};
-                V3<R> b = {__shfl_up(pq.x, off, G), __shfl_up(pq.y, off, G), __shfl_up(pq.z, off, G)};
-                if (j >= off) { ps = ps + a; pq = pq + b; }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                if (off < G) {
+                    V3<R> a = {__shfl_up(ps.x, off, 64), __shfl_up(ps.y, off, 64), __shfl_up(ps.z, off, 64)};
+                    V3<R> b = {__shfl_up(pq.x, off, 64), __shfl_up(pq.y, off, 64), __shfl_up(pq.z, off, 64)};
+                    if (j >= off) { ps = ps + a; pq = pq + b; }
+                }
             }
             const V3<R> sj = sum0 + ps, qj = sos0 + pq;
-            const R nj = n0 + (R)(j + 1);
             const uint32_t cntj = cnt0 + (uint32_t)j + 1u;
-            const bool stop = has && !need_more(cam, sj, qj, nj, cntj);
+            const bool stop = has && !need_more(cam, sj, qj, (R)cntj, cntj);
             const unsigned long long sb = __ballot(stop);
-            const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-            const unsigned long long gb = (sb >> (r * G)) & gmask;
+            const unsigned long long gb = wide ? sb : (sb >> (r * G)) & ((1ull << G) - 1ull);
             const int k_used = gb ? __ffsll((long long)gb) : G; // samples of this group that the reference would have taken
             if (has && j < k_used) stats_add(st, ls);
+            else st.c[RTMI_STAT_DISCARDED] += ls.c[RTMI_STAT_SAMPLES];
             // hand the result back to the pixel's own lane
-            const int rk = G > 1 ? __popcll(mask & ((1ull << lane) - 1ull)) : lane;
-            const int gbase = act ? rk * G : lane;
+            const bool upd = act && (!wide || lane == owner);
+            const int gbase = upd ? (wide ? 0 : lane * G) : lane;
             const int kk = __shfl(k_used, gbase, 64);
-            const int fin = act ? gbase + kk - 1 : lane;
+            const int fin = upd ? gbase + kk - 1 : lane;
             const V3<R> fs = shfl3(sj, fin), fq = shfl3(qj, fin);
-            const R fn = __shfl(nj, fin, 64);
-            if (act) { sum = fs; sos = fq; n = fn; cnt += (uint32_t)kk; }
+            if (upd) { sum = fs; sos = fq; cnt += (uint32_t)kk; }
         }
         if (valid) {
-            R inv_n = (R)1 / n;
-            size_t o = ((size_t)ly * cam.hsize + x) * 3;
-            out[o + 0] = (float)(sum.x * inv_n);
-            out[o + 1] = (float)(sum.y * inv_n);
-            out[o + 2] = (float)(sum.z * inv_n);
+            R inv = (R)1 / (R)cnt;
+            size_t o = ((size_t)out_row * cam.hsize + px) * 3;
+            out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
         }
     }
     flush_stats(st, stats);
@@ -231,10 +309,15 @@ __global__ void camera_rays_kernel(DCamera<double> cam, uint32_t seed_lo, uint32
 // ---------------------------------------------------------------------------------------------
 namespace rtmi_dev {
 template <>
-void launch_render_kernel<RTMI_REAL>(bool tree, int grid, hipStream_t st, const DScene<RTMI_REAL> &sc, const DCamera<double> &cam,
-                                     const DRender &rp, float *out, unsigned long long *stats) {
-    if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats);
-    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats);
+void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hipStream_t st, const DScene<RTMI_REAL> &sc,
+                                     const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
+                                     size_t work_bytes) {
+    DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
+    if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
+    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
+    if (!wk.hdr || grid_resample <= 0) return;
+    if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
+    else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
 }
 template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,
