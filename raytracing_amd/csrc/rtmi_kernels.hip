@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *stats) {
+__device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *__restrict__ stats) {
     if (!stats) return;
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) {
@@ -81,7 +81,12 @@ __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
 template <typename R, bool TREE>
 __global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
-                                                    unsigned long long *stats, DWork<R> wk) {
+                                                    unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
+                                                    DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy, uint32_t wk_cap) {
+    // (the queue pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
+    // written in this kernel and fetch the wave-uniform ones with scalar loads)
+    DWork<R> wk;
+    wk.hdr = wk_hdr; wk.light = wk_light; wk.heavy = wk_heavy; wk.cap = wk_cap;
     Stats st;
     stats_zero(st);
     Rng rng;
@@ -147,7 +152,10 @@ __global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DC
 // Every wave reaches the exit: the pop counters only grow and the queue lengths are fixed before the launch.
 template <typename R, bool TREE>
 __global__ void __launch_bounds__(64, RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
-                                                      unsigned long long *stats, DWork<R> wk) {
+                                                      unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
+                                                      const DWorkItem<R> *__restrict__ wk_light, const DWorkItem<R> *__restrict__ wk_heavy,
+                                                      uint32_t wk_cap) {
+    struct { uint32_t *hdr; const DWorkItem<R> *light, *heavy; uint32_t cap; } wk = {wk_hdr, wk_light, wk_heavy, wk_cap};
     Stats st;
     stats_zero(st);
     Rng rng;
@@ -313,11 +321,11 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
                                      const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
                                      size_t work_bytes) {
     DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
-    if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
-    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
+    if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     if (!wk.hdr || grid_resample <= 0) return;
-    if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
-    else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk);
+    if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
 }
 template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,
