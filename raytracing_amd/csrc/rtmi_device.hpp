@@ -25,7 +25,11 @@
 //     classified "behind" analytically instead of trusting the sign of a +-1e-5 quantity in f32.
 #pragma once
 
+#ifdef RTMI_HOST_EMUL
+#include "hip_emul.h" // tests/emul: host stand-in used to run the lane-independent kernels under sanitizers (never shipped)
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "../../include/rtmi.h"

@@ -15,6 +15,7 @@ using namespace rtmi_dev;
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+#ifndef RTMI_HOST_EMUL // the wave-cooperative kernels need a real wave (tests/emul covers the lane-independent ones)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -251,6 +252,8 @@ __global__ void __launch_bounds__(64, RTMI_WAVES) resample_kernel(DScene<R> sc, 
     flush_stats(st, stats);
 }
 
+#endif // RTMI_HOST_EMUL
+
 // World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays)
 template <typename R>
 __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
@@ -316,6 +319,7 @@ __global__ void camera_rays_kernel(DCamera<double> cam, uint32_t seed_lo, uint32
 // launchers (declared in rtmi_launch.hpp, one specialisation per build of this file)
 // ---------------------------------------------------------------------------------------------
 namespace rtmi_dev {
+#ifndef RTMI_HOST_EMUL
 template <>
 void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hipStream_t st, const DScene<RTMI_REAL> &sc,
                                      const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
@@ -327,6 +331,11 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
     if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
 }
+#else
+template <>
+void launch_render_kernel<RTMI_REAL>(bool, int, int, hipStream_t, const DScene<RTMI_REAL> &, const DCamera<double> &, const DRender &, float *,
+                                     unsigned long long *, void *, size_t) {}
+#endif
 template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,
                                     const double *origins, const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {

@@ -1,0 +1,49 @@
+"""Runs rtmi_trace_rays / rtmi_camera_rays of the HOST EMULATION build (tests/emul/librtmi_emul.so, ASan + UBSan) over
+random rays into every BASELINE scene and compares the f64 results with the oracle.  Usage (from the repo root):
+
+    make -C tests/emul && LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
+        RTMI_NO_TORCH=1 RTMI_LIB=$PWD/tests/emul/librtmi_emul.so python tests/emul/run_emul.py [n_rays]
+
+Any out-of-bounds access of a scene record, stack or queue aborts with an ASan report.  This is how a changed kernel is
+checked on the CPU before it is allowed on a GPU box."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+assert "emul" in os.environ.get("RTMI_LIB", ""), "set RTMI_LIB to the emulation library"
+import oracle_lib as orc  # noqa: E402
+from raytracing_amd import abi, scenes  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+rng = np.random.default_rng(7)
+print(abi.describe())
+for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1})]:
+    world, cam = scenes.BASELINE_SCENES[name](32, 16, **kw)
+    f = world.flatten()
+    sc = abi.Scene(world)
+    o = rng.uniform(-4, 4, (n, 3)) + np.array([0, 2.0, -3.0])
+    tgt = rng.uniform(-2, 2, (n, 3)) + np.array([0, 0.5, 0.5])
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c64, r64 = abi.trace_rays(sc, o, d, opts=abi.make_opts(precision=1))
+    c32, r32 = abi.trace_rays(sc, o, d, opts=abi.make_opts(precision=0))
+    bad = 0
+    same32 = 0
+    for i in range(n):
+        ref = orc.hit_record(f, o[i], d[i])
+        g = r64[i]
+        ok = g.hit == ref.hit and (not ref.hit or (g.leaf == ref.leaf and abs(g.t - ref.t) < 1e-7 * max(1.0, abs(ref.t)) and (g.n1, g.n2) == (ref.n1, ref.n2)))
+        if ok and name not in ("soft",):
+            ok = bool(np.all(np.abs(c64[i] - orc.color_at(f, o[i], d[i], world.max_reflection_depth)[1]) < 1e-9))
+        bad += 0 if ok else 1
+        same32 += int(r32[i].hit == ref.hit and (not ref.hit or r32[i].leaf == ref.leaf or abs(r32[i].t - ref.t) < 1e-5 * max(1.0, ref.t)))
+    px = rng.integers(0, 32, 64).astype(np.int32); py = rng.integers(0, 16, 64).astype(np.int32)
+    abi.camera_rays(cam, px, py, np.arange(64, dtype=np.int32), opts=abi.make_opts(precision=0))
+    sc.close()
+    print("%-7s rays %d  f64 mismatches vs oracle %d  f32 same leaf %.2f %%" % (name, n, bad, 100.0 * same32 / n), flush=True)
+    assert bad == 0 and same32 >= 0.995 * n
+print("emulation run clean")
