@@ -386,7 +386,7 @@ static int validate(const rtmi_scene_desc *d) {
         return fail(RTMI_ERR_INVALID, "null array with non-zero count");
     if (d->max_depth < 0 || d->max_depth > MAX_DEPTH)
         return fail(RTMI_ERR_UNSUPPORTED, "max_depth must be in [0, " + std::to_string(MAX_DEPTH) + "]");
-    if ((unsigned)d->n_leaves > ID_LEAF_MASK) return fail(RTMI_ERR_UNSUPPORTED, "too many leaves");
+    if ((unsigned)d->n_leaves >= PEND_LEAF_MASK) return fail(RTMI_ERR_UNSUPPORTED, "too many leaves (the limit is 2^26 - 2)");
     for (int i = 0; i < d->n_leaves; ++i) {
         const rtmi_leaf &l = d->leaves[i];
         if (l.kind < RTMI_SPHERE || l.kind > RTMI_SMOOTH_TRIANGLE) return fail(RTMI_ERR_INVALID, "leaf " + std::to_string(i) + ": bad kind");

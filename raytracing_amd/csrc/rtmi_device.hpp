@@ -836,6 +836,59 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
     uint32_t origin_leaf, origin_side;
 };
 
+// Where the pending rays live.  f32 (product path): the first LDS_PEND entries of every lane sit in LDS, 8 dwords per
+// entry laid out [entry][dword][lane] (conflict-free), 12 KB per wave = 12 waves per CU, which is the occupancy the
+// register budget allows anyway; deeper entries and the f64 validation mode use a per-lane array (scratch memory).
+// Recursion depth 5/6 scenes therefore push nothing to HBM.  One wave per workgroup (blockDim.x == 64) is assumed.
+constexpr int LDS_PEND = 6;
+constexpr uint32_t PEND_LEAF_BITS = 26, PEND_LEAF_MASK = (1u << PEND_LEAF_BITS) - 1u; // leaf | side << 26 | remaining << 27
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+template <typename R> struct PendingStack {
+    Pending<R> deep[sizeof(R) == 4 ? MAX_DEPTH - LDS_PEND : MAX_DEPTH];
+    int sp = 0;
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+    __device__ __forceinline__ bool full() const { return sp >= MAX_DEPTH; }
+    __device__ __forceinline__ void push(uint32_t (*lds)[8][64], const Pending<R> &e) {
+        if constexpr (sizeof(R) == 4) {
+            if (sp < LDS_PEND) {
+                const int lane = threadIdx.x & 63;
+                lds[sp][0][lane] = f2u(e.o.x); lds[sp][1][lane] = f2u(e.o.y); lds[sp][2][lane] = f2u(e.o.z);
+                lds[sp][3][lane] = f2u(e.d.x); lds[sp][4][lane] = f2u(e.d.y); lds[sp][5][lane] = f2u(e.d.z);
+                lds[sp][6][lane] = f2u(e.weight);
+                lds[sp][7][lane] = (e.origin_leaf & PEND_LEAF_MASK) | ((e.origin_side & 1u) << PEND_LEAF_BITS) | ((uint32_t)e.remaining << (PEND_LEAF_BITS + 1));
+            } else {
+                deep[sp - LDS_PEND] = e;
+            }
+        } else {
+            deep[sp] = e;
+        }
+        ++sp;
+    }
+    __device__ __forceinline__ Pending<R> pop(uint32_t (*lds)[8][64]) {
+        --sp;
+        if constexpr (sizeof(R) == 4) {
+            if (sp < LDS_PEND) {
+                const int lane = threadIdx.x & 63;
+                Pending<R> e;
+                e.o = mk<R>(u2f(lds[sp][0][lane]), u2f(lds[sp][1][lane]), u2f(lds[sp][2][lane]));
+                e.d = mk<R>(u2f(lds[sp][3][lane]), u2f(lds[sp][4][lane]), u2f(lds[sp][5][lane]));
+                e.weight = u2f(lds[sp][6][lane]);
+                const uint32_t m = lds[sp][7][lane];
+                const uint32_t leaf = m & PEND_LEAF_MASK;
+                e.origin_leaf = leaf == PEND_LEAF_MASK ? NONE : leaf;
+                e.origin_side = (m >> PEND_LEAF_BITS) & 1u;
+                e.remaining = (int32_t)(m >> (PEND_LEAF_BITS + 1));
+                return e;
+            }
+            return deep[sp - LDS_PEND];
+        } else {
+            return deep[sp];
+        }
+    }
+};
+
 // World::is_shadowed (world.rs:172-180)
 template <typename R, bool TREE>
 __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<R> &in, V3<R> p, uint32_t origin_leaf, uint32_t origin_side,
@@ -862,8 +915,8 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
     R weight = (R)1;
     uint32_t origin_leaf = NONE, origin_side = 0;
     int cls = RTMI_STAT_PRIMARY;
-    Pending<R> stack[MAX_DEPTH];
-    int sp = 0;
+    PendingStack<R> pend;
+    __shared__ uint32_t lds_pend[sizeof(R) == 4 ? LDS_PEND : 1][8][64];
     bool first = true;
     for (;;) {
         if (cls == RTMI_STAT_PRIMARY) st.c[RTMI_STAT_PRIMARY]++;
@@ -927,11 +980,12 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
                 }
             }
             if (do_refl) {
-                if (do_refr && sp < MAX_DEPTH) {
-                    stack[sp].o = refr_ray.o; stack[sp].d = refr_ray.d; stack[sp].weight = w_refr;
-                    stack[sp].remaining = remaining - 1; stack[sp].origin_leaf = h.leaf;
-                    stack[sp].origin_side = c.side_plus ? 0u : SIDE_PLUS; // under_point: the other side
-                    ++sp;
+                if (do_refr && !pend.full()) {
+                    Pending<R> e;
+                    e.o = refr_ray.o; e.d = refr_ray.d; e.weight = w_refr;
+                    e.remaining = remaining - 1; e.origin_leaf = h.leaf;
+                    e.origin_side = c.side_plus ? 0u : SIDE_PLUS; // under_point: the other side
+                    pend.push(lds_pend, e);
                 }
                 ray.d = ray.d - c.normalv * ((R)2 * dot(ray.d, c.normalv)); // reflectv, ray.rs:84
                 ray.o = over_point;
@@ -947,10 +1001,10 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
         }
         first = false;
         if (!spawned) {
-            if (sp == 0) break;
-            --sp;
-            ray.o = stack[sp].o; ray.d = stack[sp].d; weight = stack[sp].weight;
-            remaining = stack[sp].remaining; origin_leaf = stack[sp].origin_leaf; origin_side = stack[sp].origin_side;
+            if (pend.empty()) break;
+            const Pending<R> e = pend.pop(lds_pend);
+            ray.o = e.o; ray.d = e.d; weight = e.weight;
+            remaining = e.remaining; origin_leaf = e.origin_leaf; origin_side = e.origin_side;
             cls = RTMI_STAT_REFRACTION;
         }
     }

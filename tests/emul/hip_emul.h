@@ -16,6 +16,7 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__ static
 
 struct dim3 {
     unsigned x, y, z;
