@@ -192,10 +192,13 @@ def main():
                        "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "render_kernel<float>" if prec == 0 else "render_kernel<double>", "kernel_ms": k_ms,
+                         "kernel": "render_kernel<%s> + resample_kernel<%s> (the two launches of one rtmi_render_device call; "
+                                   "rocprofv3 averages: profiles/)" % (a.precision, a.precision), "kernel_ms": k_ms,
                          "algorithmic_flops_per_launch": flops_launch,
                          "note": "FP32 vector (VALU) roofline, no MFMA on this path; algorithmic FLOPs = reference "
-                                 "arithmetic per event (DESIGN.md 'FLOP accounting'), rank 0's launch"},
+                                 "arithmetic per event (DESIGN.md 'Roofline and accounting'), rank 0's launch; kernel_ms = HIP "
+                                 "events on the render stream around the call; traffic = HBM bytes per call from PMC passes "
+                                 "(profiles/traffic.json)"},
         }
         if not a.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, a, scenes)

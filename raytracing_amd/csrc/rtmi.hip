@@ -59,8 +59,8 @@ template <typename R> struct DeviceArrays {
 // created with the first scene on the device and freed with the last, so that rendering itself allocates nothing.
 // A stream is bound to a slot the first time it renders; work on one stream is ordered, so one slot per stream is
 // race-free, and renders on different streams use different slots.
-constexpr int WORK_SLOTS = 8;
-constexpr size_t WORK_BYTES = 32u << 20;
+constexpr int WORK_SLOTS = 4;
+constexpr size_t WORK_BYTES = 512u << 20; // 2 x 6.7 M queued pixels (f32): most of a 3840x2160 frame per queue; 2 GB of 288 GB per device
 constexpr int MAX_DEVICES = 64;
 struct WorkPool {
     int refs = 0;
@@ -483,6 +483,12 @@ static int check_camera(const rtmi_camera *c) {
     return RTMI_OK;
 }
 
+#ifndef RTMI_GRID_PER_CU
+#define RTMI_GRID_PER_CU 32 // waves of the first pass per CU (they stride over the tiles) when a tile visit is short
+#endif
+#ifndef RTMI_GRID_PER_CU_MANY
+#define RTMI_GRID_PER_CU_MANY 96 // ... and when every pixel takes several samples per visit
+#endif
 #ifndef RTMI_RESAMPLE_WAVES
 #define RTMI_RESAMPLE_WAVES 3 // waves per SIMD of the second pass's persistent grid
 #endif
@@ -502,7 +508,12 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.tiles_x = (c->hsize + 7) / 8;
     rp.local_tile_rows8 = (rows + 7) / 8;
     rp.n_tiles = rp.tiles_x * rp.local_tile_rows8;
-    int grid = std::min(rp.n_tiles, s->num_cu * 32);
+    // Waves stride over the tiles.  More waves than the 12 resident per CU lets the hardware dispatcher balance uneven tiles
+    // (measured on chapter-11a at 3840x2160: 96 per CU beats 32 by 11 % with 5 samples per tile visit), but each extra wave
+    // costs its launch, which dominates when a tile visit is a single sample (32 per CU beats 96 by 50 % there).
+    const int first_samples = (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples;
+    const int per_cu = first_samples >= 4 ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU;
+    int grid = std::min(rp.n_tiles, s->num_cu * per_cu);
     bool f64 = o && o->precision == RTMI_PRECISION_F64;
     if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
     const bool tree = s->h32.root_child_count != 0;
@@ -515,7 +526,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     if (open_ended) {
         lock.lock(); // held until both kernels are enqueued: calls sharing a stream must not interleave their launches
         work = pool_slot(s->device, st);
-        if (!work) return fail(RTMI_ERR_UNSUPPORTED, "more than 8 streams are rendering on this device (one work-queue slot per stream)");
+        if (!work) return fail(RTMI_ERR_UNSUPPORTED, "more than 4 streams are rendering on this device (one work-queue slot per stream)");
         HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st));
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;

@@ -8,9 +8,15 @@ namespace rtmi_dev {
 // every lane finishes its own pixel.
 constexpr size_t WORK_HEADER_BYTES = 256;
 enum { WK_LIGHT_COUNT = 0, WK_HEAVY_COUNT = 1, WK_LIGHT_HEAD = 2, WK_HEAVY_HEAD = 3 };
+#ifndef RTMI_LIGHT_NEED
 #define RTMI_LIGHT_NEED 24  // predicted further samples up to which a pixel goes to the light queue
+#endif
+#ifndef RTMI_LIGHT_BATCH
 #define RTMI_LIGHT_BATCH 8  // light pixels per wave (a power of two)
+#endif
+#ifndef RTMI_LIGHT_ROUNDS
 #define RTMI_LIGHT_ROUNDS 4 // rounds a light batch runs 8 lanes per pixel before its leftovers get the whole wave
+#endif
 template <typename R> struct DWorkItem {
     uint32_t px, py, out_row, cnt; // global pixel, row in this rank's compact buffer, samples taken so far
     R sum[3], sos[3];              // running sum and sum of squares (camera.rs:277-279)
