@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--max-samples", type=int, default=0, help="cap on samples per pixel (0 = unbounded like the reference; diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N > 1 path with several ranks sharing one GPU (rows cross through host memory)")
+    ap.add_argument("--check-frame", action="store_true", help="rank 0 also renders the whole frame alone and compares it bit for bit with the gathered one")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
     return ap.parse_args()
 
@@ -93,10 +96,16 @@ def main():
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU path)")
+    if a.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchanged tensors live
 
     build = scenes.BASELINE_SCENES[a.scene]
     world, cam = build(a.width, a.height, deterministic=(a.sampling == "1spp"))
@@ -105,9 +114,9 @@ def main():
     opts = abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
     h, v = cam.hsize(), cam.vsize()
     from raytracing_amd import tiles
-    gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=dev)
+    gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=xdev)
     assert gather.rows == abi.rank_rows(v, rank, world_size, a.tile_rows)
-    bufs = [gather.new_local(), gather.new_local()]  # double-buffered: frame i+1 renders while frame i is gathered
+    bufs = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.float32, device=dev) for _ in range(2)]  # double-buffered
     stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
     render_stream = torch.cuda.Stream(device=dev)
     ev_rendered = [torch.cuda.Event(), torch.cuda.Event()]
@@ -128,7 +137,7 @@ def main():
                 timed_events[1].record(render_stream)
             ev_rendered[b].record(render_stream)
         cur.wait_event(ev_rendered[b])
-        frames["last"] = gather.gather(bufs[b])
+        frames["last"] = gather.gather(bufs[b] if a.backend == "nccl" else bufs[b].cpu())
         ev_free[b].record(cur)
 
     def barrier():
@@ -149,8 +158,8 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = [p[0].elapsed_time(p[1]) for p in pairs]
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot = stats.clone()
+    t = torch.tensor([dt], dtype=torch.float64, device=xdev)
+    tot = stats.clone().to(xdev)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -160,6 +169,15 @@ def main():
     S = {k: int(tot[i]) for i, k in enumerate(abi.STAT_NAMES)}
     rays = S["primary"] + S["reflection"] + S["refraction"] + S["shadow"]
 
+    if a.check_frame and rank == 0:
+        whole = torch.zeros((v, h, 3), dtype=torch.float32, device=dev)
+        abi.render_device(scene, cam, abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec), whole, None,
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(whole.to(frames["last"].device), frames["last"]))
+        print("check-frame: gathered frame %s the single-rank frame" % ("EQUALS" if same else "DIFFERS FROM"), file=sys.stderr, flush=True)
+        if not same:
+            sys.exit(3)
     if rank == 0:
         k_ms = sum(kernel_ms) / len(kernel_ms)
         flops_launch = float(st_local[abi.STAT_NAMES.index("flops")]) / a.steps  # this rank's launch
