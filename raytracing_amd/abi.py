@@ -121,7 +121,7 @@ def render_host(scene, camera, opts=None):
 
 
 def render_device(scene, camera, opts, out_tensor, stats_tensor=None, stream=0):
-    """rtmi_render_device on torch tensors (out: float32 [rows,h,3] on the GPU; stats: int64 [8] or None)."""
+    """rtmi_render_device on torch tensors (out: float32 [rows,h,3] on the GPU; stats: int64 [N_STATS] or None)."""
     cam = camera.abi()
     sp = stats_tensor.data_ptr() if stats_tensor is not None else None
     check(lib().rtmi_render_device(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream), "rtmi_render_device")
