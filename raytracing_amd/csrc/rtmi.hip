@@ -116,6 +116,7 @@ struct rtmi_scene {
     DNode *nodes = nullptr;
     DCsg *csgs = nullptr;
     uint32_t *leaf_orig = nullptr;
+    DWTri *wtris = nullptr;
     DScene<float> h32;
     DScene<double> h64;
     int num_cu = 256;
@@ -277,6 +278,49 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     return RTMI_OK;
 }
 
+// World-space copies of the triangle leaves (DWTri, f32 path) in the order upload_typed numbers them (device leaf order),
+// and the NODE_ALLTRI marking of the nodes whose direct leaves are all triangles.
+static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout &L) {
+    std::vector<DWTri> out;
+    std::vector<uint32_t> tri_of_leaf(L.leaf_orig.size(), 0xFFFFFFFFu);
+    for (size_t i = 0; i < L.leaf_orig.size(); ++i) {
+        const rtmi_leaf &s = d->leaves[L.leaf_orig[i]];
+        if (s.kind != RTMI_TRIANGLE && s.kind != RTMI_SMOOTH_TRIANGLE) continue;
+        // forward (object -> world) affine map = inverse of the 3x4 part of s.inv, by cofactors
+        const double *m = s.inv;
+        const double a = m[0], b = m[1], c = m[2], e = m[4], f = m[5], g = m[6], p = m[8], q = m[9], r = m[10];
+        const double det = a * (f * r - g * q) - b * (e * r - g * p) + c * (e * q - f * p);
+        const double id = 1.0 / det;
+        const double F[9] = {(f * r - g * q) * id, (c * q - b * r) * id, (b * g - c * f) * id,
+                             (g * p - e * r) * id, (a * r - c * p) * id, (c * e - a * g) * id,
+                             (e * q - f * p) * id, (b * p - a * q) * id, (a * f - b * e) * id};
+        const double T[3] = {-(F[0] * m[3] + F[1] * m[7] + F[2] * m[11]), -(F[3] * m[3] + F[4] * m[7] + F[5] * m[11]),
+                             -(F[6] * m[3] + F[7] * m[7] + F[8] * m[11])};
+        auto lin = [&](const double *v, float *o3) { for (int k = 0; k < 3; ++k) o3[k] = (float)(F[3 * k] * v[0] + F[3 * k + 1] * v[1] + F[3 * k + 2] * v[2]); };
+        DWTri w;
+        memset(&w, 0, sizeof w);
+        double e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) { e1[k] = s.p2[k] - s.p1[k]; e2[k] = s.p3[k] - s.p1[k]; }
+        for (int k = 0; k < 3; ++k) w.p1[k] = (float)(F[3 * k] * s.p1[0] + F[3 * k + 1] * s.p1[1] + F[3 * k + 2] * s.p1[2] + T[k]);
+        lin(e1, w.e1); lin(e2, w.e2);
+        w.k = (float)det;
+        w.smooth = s.kind == RTMI_SMOOTH_TRIANGLE ? 1u : 0u;
+        tri_of_leaf[i] = (uint32_t)out.size();
+        out.push_back(w);
+    }
+    for (size_t n = 1; n < L.nodes.size(); ++n) { // node 0 is the world itself: its leaves run through the top-level loop
+        DNode &nd = L.nodes[n];
+        if ((nd.flags & NODE_CSGROOT) || nd.leaf_count == 0) continue;
+        bool all = true;
+        for (uint32_t i = 0; i < nd.leaf_count; ++i) {
+            const uint32_t t = tri_of_leaf[nd.leaf_first + i];
+            if (t == 0xFFFFFFFFu || t != tri_of_leaf[nd.leaf_first] + i || !std::isfinite(out[t].k) || out[t].k == 0.0f) all = false;
+        }
+        if (all) { nd.flags |= NODE_ALLTRI; nd.csg_count = tri_of_leaf[nd.leaf_first]; }
+    }
+    return out;
+}
+
 template <typename R>
 static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A) {
     std::vector<DLeaf<R>> leaves(L.leaf_orig.size());
@@ -370,6 +414,7 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
 template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_desc *d, const Layout &L, const DeviceArrays<R> &A, DScene<R> &h) {
     h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
     h.nodes = s->nodes; h.csgs = s->csgs; h.leaf_orig = s->leaf_orig;
+    h.wtris = sizeof(R) == 4 ? s->wtris : nullptr;
     h.n_leaves = (uint32_t)L.leaf_orig.size(); h.n_lights = (uint32_t)d->n_lights; h.n_nodes = (uint32_t)L.nodes.size();
     h.max_depth = (uint32_t)d->max_depth;
     h.root_leaf_count = L.nodes[0].leaf_count; h.root_child_first = L.nodes[0].child_first; h.root_child_count = L.nodes[0].child_count;
@@ -416,7 +461,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -436,7 +481,9 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     s->device = dev;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) s->num_cu = prop.multiProcessorCount;
+    std::vector<DWTri> wtris = world_space_triangles(desc, L);
     rc = upload(&s->nodes, L.nodes);
+    if (rc == RTMI_OK) rc = upload(&s->wtris, wtris);
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32);

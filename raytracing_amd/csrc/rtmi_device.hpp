@@ -52,6 +52,8 @@ constexpr uint32_t LEAF_FAST = 1u << 10; // f32 only: sphere under a similarity 
 constexpr uint32_t NODE_CSGROOT = 1u << 0;
 constexpr uint32_t NODE_GATED = 1u << 1;       // box is finite and proper: may be slab-tested
 constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
+constexpr uint32_t NODE_ALLTRI = 1u << 3;      // not a CSG root, every direct leaf is a triangle: wtris[csg_count + i] is leaf
+                                               // leaf_first + i in world space (f32 path)
 
 template <typename R> struct DLeaf {
     R inv[12];           // rows 0..2 of the world->object matrix
@@ -92,6 +94,16 @@ template <typename R> struct DLight {
     uint32_t pad;
 };
 
+// A triangle leaf in world space (f32 product path): the ray parameter t and the barycentrics u, v are ratios of
+// determinants, hence the same in object and world space; k = det of the world->object linear part turns the world-space
+// determinant into the object-space one that triangle.rs:243 compares with EPSILON and whose sign the spawn-side rule uses.
+struct DWTri { // 48 B
+    float p1[3], e1[3], e2[3];
+    float k;
+    uint32_t smooth; // 1 for SmoothTriangle
+    uint32_t pad;
+};
+
 struct DNode { // 48 B
     float bmin[3];
     uint32_t leaf_first;
@@ -118,6 +130,7 @@ template <typename R> struct DScene {
     const DNode *nodes;
     const DCsg *csgs;
     const uint32_t *leaf_orig; // device leaf -> index in rtmi_scene_desc.leaves
+    const DWTri *wtris;        // one per entry of tris (f32 scene only, else null)
     uint32_t n_leaves, n_lights, n_nodes, max_depth;
     uint32_t root_leaf_count, root_child_first, root_child_count, pad;
 };
@@ -613,6 +626,53 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
     }
 }
 
+// A triangle leaf of a NODE_ALLTRI node, tested in world space from its DWTri record alone: no leaf record, no ray
+// transform (triangle.rs:233-265 with the determinants expressed in world space; priced like the reference's test).
+template <int MODE>
+__device__ __forceinline__ void tri_leaf(const DWTri &w, uint32_t li, const Ray<float> &ray, uint32_t origin_leaf, uint32_t origin_side,
+                                         Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
+    const V3<float> e1 = ld3(w.e1), e2 = ld3(w.e2);
+    const V3<float> dir_cross_e2 = cross(ray.d, e2);
+    const float detw = dot(e1, dir_cross_e2), det = detw * w.k;
+    uint32_t fl = F_TRI_DET;
+    bool hit = false;
+    float t = 0;
+    if (!(abs_(det) < (float)RTMI_EPSILON)) {
+        const float f = rcp_(detw);
+        const V3<float> p1_to_origin = ray.o - ld3(w.p1);
+        const float u = f * dot(p1_to_origin, dir_cross_e2);
+        fl = F_TRI_U;
+        if (!(u < 0.0f || u > 1.0f)) {
+            const V3<float> origin_cross_e1 = cross(p1_to_origin, e1);
+            const float v = f * dot(ray.d, origin_cross_e1);
+            fl = F_TRI_V;
+            if (!(v < 0.0f || (u + v) > 1.0f)) {
+                t = f * dot(e2, origin_cross_e1);
+                hit = true;
+                fl = F_TRI_FULL;
+            }
+        }
+    }
+    st.c[RTMI_STAT_LEAF_TESTS]++;
+    st.flops += F_XFORM + fl;
+    if (hit && li == origin_leaf) { // the spawn point itself (see leaf_roots)
+        float forced = -max_(abs_(t), 1e-30f);
+        if (w.smooth) {
+            const bool plus = (origin_side & SIDE_PLUS) != 0;
+            const bool towards = plus ? det < 0.0f : det > 0.0f;
+            if (towards) forced = -forced;
+        }
+        t = forced;
+    }
+    if (MODE == MODE_COLLECT) {
+        const bool front = hit && ((li == hit_leaf) ? (0u < hit_ord) : (t < t_limit));
+        if (li == hit_leaf) open.hit_parity = front ? 1u : 0u;
+        if (front) open_candidate(open, li, hit_leaf, t);
+    } else if (hit && t >= 0.0f && t < t_limit && t < best.t) {
+        best.t = t; best.leaf = li; best.ord = 0u;
+    }
+}
+
 // World::intersect + hit (world.rs:145-156, ray.rs:143-154) / intersect_shadow + is_shadowed
 // (world.rs:158-180) / the container walk of ray.rs:111-140, as one traversal in three modes.
 //   MODE_CLOSEST: best = min t >= 0.            t_limit = +inf
@@ -647,8 +707,17 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
         if (nd.flags & NODE_CSGROOT) {
             csg_root<R, MODE>(sc, nd, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         } else {
-            for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li)
-                plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            bool done = false;
+            if constexpr (sizeof(R) == 4) {
+                if (nd.flags & NODE_ALLTRI) {
+                    for (uint32_t i = 0; i < nd.leaf_count; ++i)
+                        tri_leaf<MODE>(sc.wtris[nd.csg_count + i], nd.leaf_first + i, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+                    done = true;
+                }
+            }
+            if (!done)
+                for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li)
+                    plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             for (uint32_t c = nd.child_count; c-- > 0;) {
                 if (sp < NODE_STACK) stack[sp++] = nd.child_first + c;
                 else st.c[RTMI_STAT_OVERFLOW] = 1;
