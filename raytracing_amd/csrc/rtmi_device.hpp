@@ -673,6 +673,13 @@ __device__ __forceinline__ void tri_leaf(const DWTri &w, uint32_t li, const Ray<
     }
 }
 
+// LDS part of the traversal stack (one array per kernel: the three traversal modes of a wave never run at the same time)
+constexpr int LDS_NODES = 16;
+__device__ __forceinline__ uint32_t (*lds_node_stack())[64] {
+    __shared__ uint32_t s_nodes[LDS_NODES][64];
+    return s_nodes;
+}
+
 // World::intersect + hit (world.rs:145-156, ray.rs:143-154) / intersect_shadow + is_shadowed
 // (world.rs:158-180) / the container walk of ray.rs:111-140, as one traversal in three modes.
 //   MODE_CLOSEST: best = min t >= 0.            t_limit = +inf
@@ -688,11 +695,20 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
     }
     if (!TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
     if (sc.root_child_count == 0) return;
-    uint32_t stack[NODE_STACK];
+    // node stack: the first LDS_NODES entries of every lane in LDS ([entry][lane]), deeper ones in scratch
+    uint32_t (*lds)[64] = lds_node_stack();
+    const int lane = threadIdx.x & 63;
+    uint32_t deep[NODE_STACK - LDS_NODES];
     int sp = 0;
-    for (uint32_t c = sc.root_child_count; c-- > 0;) stack[sp++] = sc.root_child_first + c;
+    for (uint32_t c = sc.root_child_count; c-- > 0;) {
+        const uint32_t v = sc.root_child_first + c;
+        if (sp < LDS_NODES) lds[sp][lane] = v; else deep[sp - LDS_NODES] = v;
+        ++sp;
+    }
     while (sp > 0) {
-        const DNode nd = sc.nodes[stack[--sp]];
+        --sp;
+        const uint32_t top = sp < LDS_NODES ? lds[sp][lane] : deep[sp - LDS_NODES];
+        const DNode nd = sc.nodes[top];
         if (MODE == MODE_ANY && !(nd.flags & NODE_CAST_SHADOW)) continue;
         if (nd.flags & NODE_GATED) {
             // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its
@@ -719,7 +735,9 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
                 for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li)
                     plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             for (uint32_t c = nd.child_count; c-- > 0;) {
-                if (sp < NODE_STACK) stack[sp++] = nd.child_first + c;
+                const uint32_t v = nd.child_first + c;
+                if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
+                else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
                 else st.c[RTMI_STAT_OVERFLOW] = 1;
             }
         }
@@ -909,13 +927,15 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
 // entry laid out [entry][dword][lane] (conflict-free), 12 KB per wave = 12 waves per CU, which is the occupancy the
 // register budget allows anyway; deeper entries and the f64 validation mode use a per-lane array (scratch memory).
 // Recursion depth 5/6 scenes therefore push nothing to HBM.  One wave per workgroup (blockDim.x == 64) is assumed.
-constexpr int LDS_PEND = 6;
+constexpr int LDS_PEND = 6;      // flat scenes
+constexpr int LDS_PEND_TREE = 4; // tree scenes share the 12 KB with the node stack (LDS_NODES)
 constexpr uint32_t PEND_LEAF_BITS = 26, PEND_LEAF_MASK = (1u << PEND_LEAF_BITS) - 1u; // leaf | side << 26 | remaining << 27
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 
-template <typename R> struct PendingStack {
-    Pending<R> deep[sizeof(R) == 4 ? MAX_DEPTH - LDS_PEND : MAX_DEPTH];
+template <typename R, int LP> struct PendingStack {
+    static constexpr int LDS_PEND = LP; // (shadows the namespace constant inside this class)
+    Pending<R> deep[sizeof(R) == 4 ? MAX_DEPTH - LP : MAX_DEPTH];
     int sp = 0;
     __device__ __forceinline__ bool empty() const { return sp == 0; }
     __device__ __forceinline__ bool full() const { return sp >= MAX_DEPTH; }
@@ -984,8 +1004,9 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
     R weight = (R)1;
     uint32_t origin_leaf = NONE, origin_side = 0;
     int cls = RTMI_STAT_PRIMARY;
-    PendingStack<R> pend;
-    __shared__ uint32_t lds_pend[sizeof(R) == 4 ? LDS_PEND : 1][8][64];
+    constexpr int LP = TREE ? LDS_PEND_TREE : LDS_PEND;
+    PendingStack<R, LP> pend;
+    __shared__ uint32_t lds_pend[sizeof(R) == 4 ? LP : 1][8][64];
     bool first = true;
     for (;;) {
         if (cls == RTMI_STAT_PRIMARY) st.c[RTMI_STAT_PRIMARY]++;
