@@ -477,15 +477,18 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris
 // ---------------------------------------------------------------------------------------------
 // Aabb::intersect (aabb.rs:45-70,130-141) on a conservatively padded f32 box
 // ---------------------------------------------------------------------------------------------
-template <typename R> __device__ __forceinline__ bool slab(const DNode &nd, const Ray<R> &ray, R t_lo, R t_hi) {
-    R o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+// inv_d: 1/d per axis (f32 path: computed once per ray; (lo - o) * (1/d) has the same infinities and NaNs as the division)
+template <typename R> __device__ __forceinline__ bool slab(const DNode &nd, const Ray<R> &ray, V3<R> inv_d, R t_lo, R t_hi) {
+    R o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
     R tmin = -Lim<R>::inf(), tmax = Lim<R>::inf();
     bool ok = true;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         R lo = (R)nd.bmin[ax], hi = (R)nd.bmax[ax];
         if (d[ax] == (R)0 && (o[ax] < lo || o[ax] > hi)) ok = false;
-        R a0 = div_(lo - o[ax], d[ax]), a1 = div_(hi - o[ax], d[ax]);
+        R a0, a1;
+        if constexpr (sizeof(R) == 4) { a0 = (lo - o[ax]) * id[ax]; a1 = (hi - o[ax]) * id[ax]; }
+        else { a0 = div_(lo - o[ax], d[ax]); a1 = div_(hi - o[ax], d[ax]); }
         tmin = max_(tmin, min_(a0, a1));
         tmax = min_(tmax, max_(a0, a1));
     }
@@ -531,12 +534,12 @@ template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op
 // buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
 // its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
 template <typename R, int MODE>
-__device__ void csg_root(const DScene<R> &sc, const DNode &nd, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
-                         uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+__device__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
+                         Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     R bt[CSG_BUF];
     uint32_t bid[CSG_BUF];
     int k = 0;
-    for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li) {
+    for (uint32_t li = leaf_first; li < leaf_first + leaf_count; ++li) {
         const DLeaf<R> &g = sc.leaves[li];
         if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) continue;
         R t[4], u, v;
@@ -705,41 +708,57 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
         if (sp < LDS_NODES) lds[sp][lane] = v; else deep[sp - LDS_NODES] = v;
         ++sp;
     }
-    while (sp > 0) {
-        --sp;
-        const uint32_t top = sp < LDS_NODES ? lds[sp][lane] : deep[sp - LDS_NODES];
-        const DNode nd = sc.nodes[top];
-        if (MODE == MODE_ANY && !(nd.flags & NODE_CAST_SHADOW)) continue;
-        if (nd.flags & NODE_GATED) {
-            // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its
-            // negative-t roots for the in/out state); collect: anything in front of the hit counts
-            R hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
-            R lo = (MODE == MODE_COLLECT) ? -Lim<R>::inf() : (R)0;
-            st.c[RTMI_STAT_AABB_TESTS]++;
-            st.flops += F_AABB;
-            if (!slab(nd, ray, lo, hi)) continue;
+    V3<R> inv_d = mk<R>(0, 0, 0);
+    if constexpr (sizeof(R) == 4) inv_d = mk<R>(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+    // "while-while" traversal: every lane first walks inner nodes until it holds a node with leaves (lanes that found one
+    // wait for the others), then the wave tests leaves together - instead of lanes at inner nodes idling through their
+    // neighbours' triangle loops.
+    for (;;) {
+        uint32_t w_first = 0, w_count = 0, w_flags = 0, w_aux = 0;
+        bool have = false;
+        while (sp > 0 && !have) {
+            --sp;
+            const uint32_t top = sp < LDS_NODES ? lds[sp][lane] : deep[sp - LDS_NODES];
+            const DNode nd = sc.nodes[top];
+            if (MODE == MODE_ANY && !(nd.flags & NODE_CAST_SHADOW)) continue;
+            if (nd.flags & NODE_GATED) {
+                // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its
+                // negative-t roots for the in/out state); collect: anything in front of the hit counts
+                R hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
+                R lo = (MODE == MODE_COLLECT) ? -Lim<R>::inf() : (R)0;
+                st.c[RTMI_STAT_AABB_TESTS]++;
+                st.flops += F_AABB;
+                if (!slab(nd, ray, inv_d, lo, hi)) continue;
+            }
+            st.c[RTMI_STAT_NODE_VISITS]++;
+            if (!(nd.flags & NODE_CSGROOT)) {
+                for (uint32_t c = nd.child_count; c-- > 0;) {
+                    const uint32_t v = nd.child_first + c;
+                    if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
+                    else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
+                    else st.c[RTMI_STAT_OVERFLOW] = 1;
+                }
+            }
+            if ((nd.flags & NODE_CSGROOT) || nd.leaf_count) {
+                w_first = nd.leaf_first; w_count = nd.leaf_count; w_flags = nd.flags; w_aux = nd.csg_count;
+                have = true;
+            }
         }
-        st.c[RTMI_STAT_NODE_VISITS]++;
-        if (nd.flags & NODE_CSGROOT) {
-            csg_root<R, MODE>(sc, nd, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+        if (!have) break;
+        if (w_flags & NODE_CSGROOT) {
+            csg_root<R, MODE>(sc, w_first, w_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         } else {
             bool done = false;
             if constexpr (sizeof(R) == 4) {
-                if (nd.flags & NODE_ALLTRI) {
-                    for (uint32_t i = 0; i < nd.leaf_count; ++i)
-                        tri_leaf<MODE>(sc.wtris[nd.csg_count + i], nd.leaf_first + i, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+                if (w_flags & NODE_ALLTRI) {
+                    for (uint32_t i = 0; i < w_count; ++i)
+                        tri_leaf<MODE>(sc.wtris[w_aux + i], w_first + i, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
                     done = true;
                 }
             }
             if (!done)
-                for (uint32_t li = nd.leaf_first; li < nd.leaf_first + nd.leaf_count; ++li)
+                for (uint32_t li = w_first; li < w_first + w_count; ++li)
                     plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
-            for (uint32_t c = nd.child_count; c-- > 0;) {
-                const uint32_t v = nd.child_first + c;
-                if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
-                else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
-                else st.c[RTMI_STAT_OVERFLOW] = 1;
-            }
         }
         if (MODE == MODE_ANY && best.leaf != NONE) return;
     }
