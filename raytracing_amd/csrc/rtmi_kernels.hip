@@ -9,7 +9,10 @@ using namespace rtmi_dev;
 #error "compile with -DRTMI_REAL=float or -DRTMI_REAL=double"
 #endif
 #ifndef RTMI_WAVES
-#define RTMI_WAVES 3 // minimum waves per SIMD the render kernels are register-allocated for
+#define RTMI_WAVES 3 // minimum waves per SIMD the flat-scene render kernels are register-allocated for (168 VGPRs)
+#endif
+#ifndef RTMI_WAVES_TREE
+#define RTMI_WAVES_TREE 3 // ... and the tree-scene kernels
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -81,7 +84,7 @@ __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<
 // appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
 template <typename R, bool TREE>
-__global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+__global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy, uint32_t wk_cap) {
     // (the queue pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(64, RTMI_WAVES) render_kernel(DScene<R> sc, DC
 // at which the reference's sequential loop would have stopped.  Samples past it are discarded, their rays not counted.
 // Every wave reaches the exit: the pop counters only grow and the queue lengths are fixed before the launch.
 template <typename R, bool TREE>
-__global__ void __launch_bounds__(64, RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+__global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                       const DWorkItem<R> *__restrict__ wk_light, const DWorkItem<R> *__restrict__ wk_heavy,
                                                       uint32_t wk_cap) {
