@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path with several ranks sharing one GPU (rows cross through host memory)")
+    ap.add_argument("--gather", default="f32", choices=["f32", "rgb8"],
+                    help="what crosses xGMI: the float canvas (default, what Camera::render returns) or Color::to_u8 bytes made on the device")
     ap.add_argument("--check-frame", action="store_true", help="rank 0 also renders the whole frame alone and compares it bit for bit with the gathered one")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
     return ap.parse_args()
@@ -114,9 +116,10 @@ def main():
     opts = abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
     h, v = cam.hsize(), cam.vsize()
     from raytracing_amd import tiles
-    gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=xdev)
+    gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=xdev, dtype=torch.uint8 if a.gather == "rgb8" else torch.float32)
     assert gather.rows == abi.rank_rows(v, rank, world_size, a.tile_rows)
     bufs = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.float32, device=dev) for _ in range(2)]  # double-buffered
+    bufs8 = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if a.gather == "rgb8" else None
     stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
     render_stream = torch.cuda.Stream(device=dev)
     ev_rendered = [torch.cuda.Event(), torch.cuda.Event()]
@@ -137,7 +140,11 @@ def main():
                 timed_events[1].record(render_stream)
             ev_rendered[b].record(render_stream)
         cur.wait_event(ev_rendered[b])
-        frames["last"] = gather.gather(bufs[b] if a.backend == "nccl" else bufs[b].cpu())
+        send = bufs[b]
+        if a.gather == "rgb8":  # Color::to_u8 on the device (color.rs:53-60): 3 B per pixel over the links instead of 12
+            abi.tonemap_u8_device(bufs[b], bufs8[b], cur.cuda_stream)
+            send = bufs8[b]
+        frames["last"] = gather.gather(send if a.backend == "nccl" else send.cpu())
         ev_free[b].record(cur)
 
     def barrier():
@@ -174,6 +181,11 @@ def main():
         abi.render_device(scene, cam, abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec), whole, None,
                           torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
+        if a.gather == "rgb8":
+            whole8 = torch.zeros((v, h, 3), dtype=torch.uint8, device=dev)
+            abi.tonemap_u8_device(whole, whole8, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            whole = whole8
         same = bool(torch.equal(whole.to(frames["last"].device), frames["last"]))
         print("check-frame: gathered frame %s the single-rank frame" % ("EQUALS" if same else "DIFFERS FROM"), file=sys.stderr, flush=True)
         if not same:
@@ -204,7 +216,7 @@ def main():
             "dtype": a.precision,
             "data": "synthetic",
             "config": {"workload": workload_name(a), "scene": a.scene, "max_depth": int(world.max_reflection_depth),
-                       "seed": a.seed, "sharding": "8-row tiles round-robin, RCCL gather to rank 0" if world_size > 1 else "none",
+                       "seed": a.seed, "sharding": ("8-row tiles round-robin, %s gather of %s rows to rank 0" % (a.backend, a.gather)) if world_size > 1 else "none",
                        "rays_per_step": rays // a.steps, "samples_per_step": S["samples"] // a.steps,
                        "discarded_samples_per_step": S["discarded"] // a.steps,
                        "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},

@@ -13,12 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,nranks", [("ch11a", 2), ("dice", 3)])
-def test_sharded_frame_equals_single_rank_frame(scene, nranks):
-    port = 29600 + nranks
+@pytest.mark.parametrize("scene,nranks,gather", [("ch11a", 2, "f32"), ("dice", 3, "f32"), ("ch11b", 2, "rgb8")])
+def test_sharded_frame_equals_single_rank_frame(scene, nranks, gather):
+    port = 29600 + nranks + (10 if gather == "rgb8" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--backend", "gloo", "--check-frame",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--scene", scene, "--width", "480", "--height", "270"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--scene", scene, "--width", "480", "--height", "270", "--gather", gather]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "gathered frame EQUALS" in r.stderr
