@@ -149,8 +149,8 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
 }
 
 // Camera::multisample's open-ended loop (camera.rs:290-299) for the pixels render_kernel queued.  Waves pop work until
-// both queues are empty: first the heavy queue, one pixel per wave (longest jobs first), then the light queue, eight
-// pixels per wave.  A group of G lanes computes a pixel's next G samples at once (counter RNG: sample s of a pixel
+// both queues are empty: first the heavy queue, one pixel per wave (longest jobs first), then the light queue,
+// RTMI_LIGHT_BATCH pixels per wave.  A group of G lanes computes a pixel's next G samples at once (counter RNG: sample s of a pixel
 // does not depend on who computes it); a prefix sum over the group in sample order then finds the first sample count
 // at which the reference's sequential loop would have stopped.  Samples past it are discarded, their rays not counted.
 // Every wave reaches the exit: the pop counters only grow and the queue lengths are fixed before the launch.
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
         // ---- rounds -----------------------------------------------------------------------------------------
         // The chunking of a pixel's samples depends on that pixel alone (never on its neighbours in the batch or on
         // the order of the queue), so its sums - and with them the image - are reproducible bit for bit:
-        // heavy pixels take 64 samples per round; light pixels RTMI_LIGHT_ROUNDS rounds of 8, then 64 per round, one
-        // pixel after the other.
+        // heavy pixels take 64 samples per round; light pixels RTMI_LIGHT_ROUNDS rounds of 64 / RTMI_LIGHT_BATCH, then 64
+        // per round, one pixel after the other.
         for (int round = 0;; ++round) {
             const bool act = valid && need_more(cam, sum, sos, (R)cnt, cnt);
             const unsigned long long mask = __ballot(act);
