@@ -352,6 +352,48 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
                 g.kind |= LEAF_FAST;
             }
         }
+        // bounding sphere of a finite leaf below a node (top-level leaves are few and usually large: not worth a test)
+        if (sizeof(R) == 4 && !(g.kind & LEAF_FAST) && i >= L.nodes[0].leaf_count) {
+            // object-space bound: centre c_o, radius r_o
+            double co[3] = {0, 0, 0}, ro = -1;
+            if (s.kind == RTMI_SPHERE) ro = 1.0;
+            else if (s.kind == RTMI_CUBE) ro = std::sqrt(3.0);
+            else if ((s.kind == RTMI_CYLINDER || s.kind == RTMI_CONE) && std::isfinite(s.minimum) && std::isfinite(s.maximum) && s.maximum >= s.minimum) {
+                co[1] = 0.5 * (s.minimum + s.maximum);
+                const double hh = 0.5 * (s.maximum - s.minimum);
+                const double rad = s.kind == RTMI_CYLINDER ? 1.0 : std::max(std::fabs(s.minimum), std::fabs(s.maximum));
+                ro = std::sqrt(hh * hh + rad * rad);
+            } else if (s.kind == RTMI_TRIANGLE || s.kind == RTMI_SMOOTH_TRIANGLE) {
+                for (int a = 0; a < 3; ++a) co[a] = (s.p1[a] + s.p2[a] + s.p3[a]) / 3.0;
+                for (const double *p : {s.p1, s.p2, s.p3}) {
+                    double d2 = 0;
+                    for (int a = 0; a < 3; ++a) d2 += (p[a] - co[a]) * (p[a] - co[a]);
+                    ro = std::max(ro, std::sqrt(d2));
+                }
+            }
+            // to world space through the forward map F = inverse of the 3x4 part of s.inv; |F v| <= ||F||_F |v|
+            const double *m = s.inv;
+            const double a0 = m[0], b0 = m[1], c0 = m[2], e0 = m[4], f0 = m[5], g0 = m[6], p0 = m[8], q0 = m[9], r0 = m[10];
+            const double det = a0 * (f0 * r0 - g0 * q0) - b0 * (e0 * r0 - g0 * p0) + c0 * (e0 * q0 - f0 * p0);
+            if (ro >= 0 && std::isfinite(det) && det != 0) {
+                const double id = 1.0 / det;
+                const double F[9] = {(f0 * r0 - g0 * q0) * id, (c0 * q0 - b0 * r0) * id, (b0 * g0 - c0 * f0) * id,
+                                     (g0 * p0 - e0 * r0) * id, (a0 * r0 - c0 * p0) * id, (c0 * e0 - a0 * g0) * id,
+                                     (e0 * q0 - f0 * p0) * id, (b0 * p0 - a0 * q0) * id, (a0 * f0 - b0 * e0) * id};
+                double fro = 0, cw[3];
+                for (int k = 0; k < 9; ++k) fro += F[k] * F[k];
+                for (int k = 0; k < 3; ++k) {
+                    const double x = co[0] - m[3], y = co[1] - m[7], z = co[2] - m[11]; // F (c_o - t)
+                    cw[k] = F[3 * k] * x + F[3 * k + 1] * y + F[3 * k + 2] * z;
+                }
+                const double rw = std::sqrt(fro) * ro * (1.0 + 1e-4) + 1e-6;
+                if (std::isfinite(rw) && std::isfinite(cw[0]) && std::isfinite(cw[1]) && std::isfinite(cw[2])) {
+                    for (int k = 0; k < 3; ++k) g.fast[k] = (R)cw[k];
+                    g.fast[3] = (R)(rw * rw);
+                    g.kind |= LEAF_BOUND;
+                }
+            }
+        }
         if (s.kind == RTMI_TRIANGLE || s.kind == RTMI_SMOOTH_TRIANGLE) {
             DTri<R> t;
             double e1[3], e2[3];

@@ -47,6 +47,8 @@ constexpr uint32_t LEAF_KIND_MASK = 0xFFu;
 constexpr uint32_t LEAF_CLOSED = 1u << 8;
 constexpr uint32_t LEAF_CAST_SHADOW = 1u << 9;
 constexpr uint32_t LEAF_FAST = 1u << 10; // f32 only: sphere under a similarity transform, tested in world space (fast[])
+constexpr uint32_t LEAF_BOUND = 1u << 11; // f32 only: fast[] = a world-space sphere (centre, radius^2, slightly inflated) that
+                                          // contains the leaf; a ray whose line misses it has no roots (leaves below nodes only)
 
 // node.flags
 constexpr uint32_t NODE_CSGROOT = 1u << 0;
@@ -58,7 +60,7 @@ constexpr uint32_t NODE_ALLTRI = 1u << 3;      // not a CSG root, every direct l
 template <typename R> struct DLeaf {
     R inv[12];           // rows 0..2 of the world->object matrix
     R minimum, maximum;  // cylinder / cone
-    R fast[4];           // LEAF_FAST: world-space centre and squared radius
+    R fast[4];           // LEAF_FAST: world-space centre and squared radius; LEAF_BOUND: bounding sphere
     uint32_t kind;       // kind | LEAF_CLOSED | LEAF_CAST_SHADOW | LEAF_FAST
     uint32_t material;
     uint32_t tri;        // index into tris (triangle kinds)
@@ -415,6 +417,14 @@ __device__ __forceinline__ V3<R> local_normal(const DLeaf<R> &g, const DTri<R> *
 // How a ray was spawned on its origin leaf (bits above the leaf index in Ray bookkeeping)
 constexpr uint32_t SIDE_PLUS = 1u; // smooth triangles: the spawn point lies on the +(e2 x e1) side of the triangle's plane
 
+// squared distance of the ray's line from a sphere's centre against its squared radius
+template <typename R> __device__ __forceinline__ bool line_misses_sphere(const Ray<R> &ray, const R *sph) {
+    const V3<R> oc = ray.o - ld3(sph);
+    const R a = dot(ray.d, ray.d), hb = dot(ray.d, oc);
+    const V3<R> l = oc - ray.d * (hb * rcp_(a));
+    return dot(l, l) > sph[3];
+}
+
 // World-space intersection of one leaf: Shape::intersect (shapes/mod.rs:252-255).  When the ray was spawned on
 // this very leaf, its root nearest to zero IS the spawn point (|t| ~ 1e-5) and its sign is known analytically:
 //  * geometric normals (everything but smooth triangles): the spawn point was pushed off the surface along the
@@ -444,6 +454,10 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris
             n = 2;
             fl = F_SPHERE_HIT;
         }
+    } else if (sizeof(R) == 4 && (g.kind & LEAF_BOUND) && !is_origin && line_misses_sphere(ray, g.fast)) {
+        // no roots; priced like the reference's own (missing) test of this leaf
+        fl = kind == RTMI_SPHERE ? F_SPHERE_MISS : kind == RTMI_CUBE ? F_CUBE : kind >= RTMI_TRIANGLE ? F_TRI_U
+             : (g.kind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
     } else if (kind == RTMI_PLANE) { // plane.rs:35-44 needs the y row of the object-space ray only
         const R oy = g.inv[4] * ray.o.x + g.inv[5] * ray.o.y + g.inv[6] * ray.o.z + g.inv[7];
         const R dy = g.inv[4] * ray.d.x + g.inv[5] * ray.d.y + g.inv[6] * ray.d.z;
