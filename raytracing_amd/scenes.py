@@ -121,6 +121,36 @@ def chapter15(h=900, v=450, deterministic=False, lite=False, depth_of_field=Fals
     return w, cam
 
 
+def lights_gallery(h=300, v=150, deterministic=False, random_lights=True):
+    """Not a reference example: every light kind the Rust API offers (lights.rs: Point, Ambient, RealisticPoint, Beam and,
+    if `random_lights`, Sphere and Disc) over every primitive kind, so that the device path of each is compared with the
+    oracle (the reference itself has unit tests for Beam only).  (The stripes are shifted so that no cube face lies exactly
+    on a stripe boundary, where floor() of a rounded coordinate is a coin toss in any precision.)"""
+    w = rt.World.empty()
+    w.add_light(rt.AmbientLight(rt.color(0.05, 0.05, 0.05)))
+    w.add_light(rt.PointLight(rt.point(-6, 8, -6), rt.color(0.35, 0.3, 0.3)))
+    w.add_light(rt.RealisticPointLight(rt.point(4, 5, -3), rt.color(40, 40, 60)))
+    w.add_light(rt.Beam(rt.point(0, 9, 0), rt.vector(0, 0, 1.5), rt.vector(1.5, 0, 0), rt.color(0.5, 0.6, 0.3)))
+    if random_lights:
+        w.add_light(rt.SphereLight(rt.point(-3, 4, -4), 0.7, rt.color(0.3, 0.3, 0.3)))
+        w.add_light(rt.DiscLight(rt.point(3, 6, 2), rt.vector(-0.3, -1, -0.2).normalized(), 1.2, rt.color(60, 50, 40)))
+    floor = rt.Phong.default().with_pattern(rt.ring_pattern(rt.color(0.9, 0.9, 0.9), rt.color(0.5, 0.6, 0.7))).with_specular(0.1)
+    w.add_item(rt.plane().with_material(floor))
+    w.add_item(rt.sphere().with_transform(rt.translation(-2.5, 1, 0) * rt.scaling(1, 1, 0.6)).with_material(
+        rt.Phong.default().with_rgb(0.9, 0.3, 0.2).with_reflective(0.2)))
+    w.add_item(rt.cube().with_transform(rt.translation(0, 0.75, 1.5) * rt.rotation_y(0.6) * rt.scaling(0.75, 0.75, 0.75)).with_material(
+        rt.Phong.default().with_pattern(rt.stripe_pattern(rt.color(0.2, 0.7, 0.3), rt.color(0.9, 0.9, 0.2)).with_transform(rt.translation(0.13, 0, 0) * rt.scaling(0.25, 1, 1)))))
+    w.add_item(rt.cylinder(0.0, 1.5, True).with_transform(rt.translation(2.5, 0, 0) * rt.scaling(0.6, 1, 0.6)).with_material(
+        rt.Phong.default().with_rgb(0.2, 0.4, 0.9).with_shininess(50.0)))
+    w.add_item(rt.cone(-1.0, 0.0, True).with_transform(rt.translation(0.5, 1.0, -1.5) * rt.scaling(0.6, 1, 0.6)).with_material(
+        rt.Phong.default().with_rgb(0.8, 0.6, 0.1)))
+    w.add_item(rt.triangle(rt.point(-4, 0, 3), rt.point(-1, 0, 4), rt.point(-2.5, 3, 3.5)).with_material(
+        rt.Phong.default().with_rgb(0.7, 0.2, 0.7)))
+    w.add_item(rt.glass_sphere().with_transform(rt.translation(1.2, 0.5, -2.5) * rt.scaling(0.5, 0.5, 0.5)))
+    w.finalize_scene()
+    return w, _camera(h, v, (0.5, 4.5, -9), (0, 1, 0), se=2e-2, min_samples=4, deterministic=deterministic)
+
+
 def soft_shadow(h=900, v=450, deterministic=False):
     """rust/examples/soft_shadow.rs:12-59 — BASELINE config 4 (area light)."""
     w = rt.World.empty()
