@@ -602,7 +602,10 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     // costs its launch, which dominates when a tile visit is a single sample (32 per CU beats 96 by 50 % there).
     const int first_samples = (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples;
     const int per_cu = first_samples >= 4 ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU;
+    // ... and a wave that visits a single tile is mostly launch cost (one wave per tile: +25 % on the whole frame), which
+    // matters for the small per-rank frames of an 8-GPU run: at least 3 tiles per wave while that still fills the GPU.
     int grid = std::min(rp.n_tiles, s->num_cu * per_cu);
+    grid = std::max(std::min(grid, (rp.n_tiles + 2) / 3), std::min(rp.n_tiles, s->num_cu * 12));
     bool f64 = o && o->precision == RTMI_PRECISION_F64;
     if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
     const bool tree = s->h32.root_child_count != 0;
