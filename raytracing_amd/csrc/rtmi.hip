@@ -60,7 +60,7 @@ template <typename R> struct DeviceArrays {
 // A stream is bound to a slot the first time it renders; work on one stream is ordered, so one slot per stream is
 // race-free, and renders on different streams use different slots.
 constexpr int WORK_SLOTS = 4;
-constexpr size_t WORK_BYTES = 512u << 20; // 2 x 6.7 M queued pixels (f32): most of a 3840x2160 frame per queue; 2 GB of 288 GB per device
+constexpr size_t WORK_BYTES = (size_t)2 << 30; // 2 x 9.5 M queued pixels (f32: a whole 3840x2160 frame per queue) + 330 k units of 64 samples; 8 GB of 288 GB per device
 constexpr int MAX_DEVICES = 64;
 struct WorkPool {
     int refs = 0;

@@ -42,14 +42,25 @@ __device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long 
 // Camera::multisample's loop condition (camera.rs:281,290-291 with color_variance_of_mean, 305-310):
 // true while the pixel that has taken `cnt` samples (n == cnt as a float) must take another one.
 template <typename R> __device__ __forceinline__ bool need_more(const DCamera<double> &cam, V3<R> sum, V3<R> sos, R n, uint32_t cnt) {
+#pragma clang fp contract(off) // the same rounding wherever this is inlined: the stop decision must not depend on the kernel that takes it
     if (cnt == 0) return true;
     if (cam.max_samples > 0 && cnt >= (uint32_t)cam.max_samples) return false;
     if (n < (R)cam.min_samples) return true;
-    R inv_n = rcp_(n);
-    V3<R> mean = sum * inv_n;
-    V3<R> var = sos * inv_n - had(mean, mean);
-    R variance = div_(var.x + var.y + var.z, (R)3);
+    const R inv_n = rcp_(n);
+    const R mx = sum.x * inv_n, my = sum.y * inv_n, mz = sum.z * inv_n;
+    const R qx = sos.x * inv_n, qy = sos.y * inv_n, qz = sos.z * inv_n;
+    const R sx = mx * mx, sy = my * my, sz = mz * mz;
+    const R vx = qx - sx, vy = qy - sy, vz = qz - sz;
+    const R variance = div_((vx + vy) + vz, (R)3);
     return div_(variance, n) > (R)cam.se2;
+}
+
+// c * c per channel, never fused into the sums it is added to (see need_more)
+template <typename R> __device__ __forceinline__ V3<R> squares(V3<R> c) {
+#pragma clang fp contract(off)
+    V3<R> q;
+    q.x = c.x * c.x; q.y = c.y * c.y; q.z = c.z * c.z;
+    return q;
 }
 
 template <typename R> __device__ __forceinline__ V3<R> shfl3(V3<R> v, int src) {
@@ -77,6 +88,41 @@ __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<
     return color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
 }
 
+// The 64-sample units a pixel with these running sums would be given in a pass: what the stopping rule
+// (variance / n <= SE^2) predicts it still needs, within RTMI_SPEC_MAX and the camera's sample cap.  Only the amount
+// of work done ahead depends on this; the pixel's result does not.
+template <typename R> __device__ __forceinline__ uint32_t predict_units(const DCamera<double> &cam, V3<R> sum, V3<R> sos, uint32_t cnt) {
+    const R inv_n = rcp_((R)cnt);
+    const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean);
+    const R want = div_(var.x + var.y + var.z, (R)3 * (R)cam.se2) - (R)cnt;
+    uint32_t lim = (uint32_t)RTMI_SPEC_MAX;
+    if (cam.max_samples > 0) lim = min(lim, ((uint32_t)cam.max_samples - cnt + 63u) >> 6);
+    lim = max(lim, 1u);
+    const R units = (R)ceil(want * (R)(RTMI_SPEC_MARGIN / 64.0));
+    return units >= (R)lim ? lim : (units >= (R)1 ? (uint32_t)units : 1u); // (a NaN takes one unit)
+}
+
+// Heavy pixel `p` (its record holds the sums) gets `n` units of pass `pass` (1 .. RTMI_SPEC_PASSES), or - after the last
+// pass, or when the pass's unit list is full - goes to the last launch's sequential loop.  Called by one lane per pixel.
+template <typename R>
+__device__ __forceinline__ void push_heavy(uint32_t *__restrict__ hdr, DWorkItem<R> *__restrict__ heavy, uint32_t *__restrict__ final_idx,
+                                           uint32_t *__restrict__ unit_pixel, uint32_t unit_cap, uint32_t p, uint32_t n, int pass) {
+    if (pass <= RTMI_SPEC_PASSES) {
+        const uint32_t base = atomicAdd(&hdr[WK_UNIT_COUNT + pass], n);
+        uint32_t *up = unit_pixel + (size_t)(pass & 1) * unit_cap;
+        if (base <= unit_cap && n <= unit_cap - base) {
+            heavy[p].unit_base = base; heavy[p].n_chunks = n;
+#pragma unroll 1
+            for (uint32_t k = 0; k < n; ++k) up[base + k] = p;
+            return;
+        }
+#pragma unroll 1
+        for (uint32_t k = 0; k < n && base < unit_cap && k < unit_cap - base; ++k) up[base + k] = 0xFFFFFFFFu; // claimed, unusable
+    }
+    const uint32_t f = atomicAdd(&hdr[WK_FINAL_COUNT], 1u);
+    final_idx[f] = p; // f < cap: a heavy pixel comes here at most once
+}
+
 // Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310), first pass: one wave64 per 8x8 pixel tile,
 // waves stride over the tiles this rank owns; every pixel takes its first min_samples samples on its own lane (all 64
 // lanes busy, neighbouring rays coherent).  Pixels the reference's loop would stop at (camera.rs:290-291) are written
@@ -86,11 +132,10 @@ __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<
 template <typename R, bool TREE>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
-                                                    DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy, uint32_t wk_cap) {
-    // (the queue pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
+                                                    DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
+                                                    uint32_t wk_cap) {
+    // (the work pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
     // written in this kernel and fetch the wave-uniform ones with scalar loads)
-    DWork<R> wk;
-    wk.hdr = wk_hdr; wk.light = wk_light; wk.heavy = wk_heavy; wk.cap = wk_cap;
     Stats st;
     stats_zero(st);
     Rng rng;
@@ -111,11 +156,11 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
         bool go = valid, queued = false;
         while (go) { // wave-uniform for the first `first` iterations; afterwards only lanes without a queue slot stay
             V3<R> c = take_sample<R, TREE>(sc, cam, rng, st, x, y, cnt);
-            sum = sum + c; sos = sos + had(c, c);
+            sum = sum + c; sos = sos + squares(c);
             ++cnt;
             if (cnt < first) continue;
             bool more = need_more(cam, sum, sos, (R)cnt, cnt);
-            if (more && cnt == first && wk.hdr) { // decided once per pixel, by all such lanes of the tile together
+            if (more && cnt == first && wk_hdr) { // decided once per pixel, by all such lanes of the tile together
                 // predicted samples still to take: the loop stops when variance / n <= SE^2
                 const R inv_n = rcp_((R)cnt);
                 const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean);
@@ -125,11 +170,11 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
                 const unsigned long long mine = heavy ? mh : ml;
                 const int leader = __ffsll((long long)mine) - 1;
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&wk.hdr[heavy ? WK_HEAVY_COUNT : WK_LIGHT_COUNT], (uint32_t)__popcll(mine));
+                if (lane == leader) base = atomicAdd(&wk_hdr[heavy ? WK_HEAVY_COUNT : WK_LIGHT_COUNT], (uint32_t)__popcll(mine));
                 base = __shfl(base, leader, 64);
                 const uint32_t slot = base + (uint32_t)__popcll(mine & lt_mask);
-                if (slot < wk.cap) {
-                    DWorkItem<R> *q = (heavy ? wk.heavy : wk.light) + slot;
+                if (slot < wk_cap) {
+                    DWorkItem<R> *q = (heavy ? wk_heavy : wk_light) + slot;
                     q->px = (uint32_t)x; q->py = (uint32_t)y; q->out_row = (uint32_t)ly; q->cnt = cnt;
                     q->sum[0] = sum.x; q->sum[1] = sum.y; q->sum[2] = sum.z;
                     q->sos[0] = sos.x; q->sos[1] = sos.y; q->sos[2] = sos.z;
@@ -148,46 +193,220 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
     flush_stats(st, stats);
 }
 
-// Camera::multisample's open-ended loop (camera.rs:290-299) for the pixels render_kernel queued.  Waves pop work until
-// both queues are empty: first the heavy queue, one pixel per wave (longest jobs first), then the light queue,
-// RTMI_LIGHT_BATCH pixels per wave.  A group of G lanes computes a pixel's next G samples at once (counter RNG: sample s of a pixel
-// does not depend on who computes it); a prefix sum over the group in sample order then finds the first sample count
-// at which the reference's sequential loop would have stopped.  Samples past it are discarded, their rays not counted.
-// Every wave reaches the exit: the pop counters only grow and the queue lengths are fixed before the launch.
+// inclusive prefix sums of a colour and its square over the G lanes of a group, in lane order (the association depends
+// on the lane's place j in its group only)
+template <typename R> __device__ __forceinline__ void group_prefix(V3<R> &ps, V3<R> &pq, int G, int j) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        if (off < G) {
+            V3<R> a = {__shfl_up(ps.x, off, 64), __shfl_up(ps.y, off, 64), __shfl_up(ps.z, off, 64)};
+            V3<R> b = {__shfl_up(pq.x, off, 64), __shfl_up(pq.y, off, 64), __shfl_up(pq.z, off, 64)};
+            if (j >= off) { ps = ps + a; pq = pq + b; }
+        }
+    }
+}
+
+// One wave walks the units heavy pixel `p` was given in this pass in sample order, exactly as the sequential loop's
+// 64-sample rounds would have: same prefix sums, same stopping test at every sample count.
+// Stops the pixel (writes it out), or stores its sums and gives it units of the next pass.  Samples past the stop are
+// discarded, their rays not counted.
+template <typename R>
+__device__ __forceinline__ void sum_up_units(const DCamera<double> &cam, float *__restrict__ out, uint32_t *__restrict__ hdr,
+                                             DWorkItem<R> *__restrict__ heavy, uint32_t *__restrict__ final_idx, uint32_t *__restrict__ unit_pixel,
+                                             const DChunk<R> *chunks, uint32_t unit_cap, uint32_t p, int pass, Stats &st, int lane) {
+    DWorkItem<R> *it = heavy + p;
+    V3<R> sum = mk<R>(it->sum[0], it->sum[1], it->sum[2]), sos = mk<R>(it->sos[0], it->sos[1], it->sos[2]);
+    uint32_t cnt = it->cnt;
+    const uint32_t n = it->n_chunks, base = it->unit_base;
+    bool stopped = false;
+    uint32_t c = 0;
+    // (the next unit's record is fetched while this one is summed: the walk is a chain of short dependent steps)
+    R ncol[3];
+    uint32_t nst[CHUNK_STAT_WORDS];
+    {
+        const DChunk<R> *ch = chunks + base;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ncol[k] = ch->col[k][lane];
+#pragma unroll
+        for (int k = 0; k < CHUNK_STAT_WORDS; ++k) nst[k] = ch->st[k][lane];
+    }
+#pragma unroll 1
+    for (; c < n && !stopped; ++c) {
+        V3<R> ps = mk<R>(ncol[0], ncol[1], ncol[2]);
+        uint32_t w[CHUNK_STAT_WORDS];
+#pragma unroll
+        for (int k = 0; k < CHUNK_STAT_WORDS; ++k) w[k] = nst[k];
+        if (c + 1 < n) {
+            const DChunk<R> *ch = chunks + (base + c + 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ncol[k] = ch->col[k][lane];
+#pragma unroll
+            for (int k = 0; k < CHUNK_STAT_WORDS; ++k) nst[k] = ch->st[k][lane];
+        }
+        V3<R> pq = squares(ps);
+        group_prefix(ps, pq, 64, lane);
+        const V3<R> sj = sum + ps, qj = sos + pq;
+        const uint32_t cntj = cnt + (uint32_t)lane + 1u;
+        const unsigned long long sb = __ballot(!need_more(cam, sj, qj, (R)cntj, cntj));
+        const int k = sb ? __ffsll((long long)sb) : 64;
+        if (lane < k) {
+            st.c[RTMI_STAT_PRIMARY] += w[0] & 0xFFu; st.c[RTMI_STAT_SAMPLES] += (w[0] >> 8) & 0xFFu; st.c[RTMI_STAT_OVERFLOW] += w[0] >> 16;
+            st.c[RTMI_STAT_REFLECTION] += w[1]; st.c[RTMI_STAT_REFRACTION] += w[2];
+            st.c[RTMI_STAT_SHADOW] += w[3]; st.c[RTMI_STAT_LEAF_TESTS] += w[4];
+            st.c[RTMI_STAT_NODE_VISITS] += w[5]; st.c[RTMI_STAT_AABB_TESTS] += w[6];
+            st.flops += w[7];
+        } else st.c[RTMI_STAT_DISCARDED] += (w[0] >> 8) & 0xFFu;
+        sum = shfl3(sj, k - 1); sos = shfl3(qj, k - 1);
+        cnt += (uint32_t)k;
+        stopped = sb != 0;
+    }
+    if (c < n) st.c[RTMI_STAT_DISCARDED] += (nst[0] >> 8) & 0xFFu; // (already fetched)
+#pragma unroll 1
+    for (++c; c < n; ++c) st.c[RTMI_STAT_DISCARDED] += (chunks[base + c].st[0][lane] >> 8) & 0xFFu;
+    if (lane != 0) return;
+    if (stopped) {
+        const R inv = (R)1 / (R)cnt;
+        const size_t o = ((size_t)it->out_row * cam.hsize + it->px) * 3;
+        out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
+    } else {
+        it->cnt = cnt;
+        it->sum[0] = sum.x; it->sum[1] = sum.y; it->sum[2] = sum.z;
+        it->sos[0] = sos.x; it->sos[1] = sos.y; it->sos[2] = sos.z;
+        push_heavy<R>(hdr, heavy, final_idx, unit_pixel, unit_cap, p, predict_units(cam, sum, sos, cnt), pass + 1);
+    }
+}
+
+// After each unit pass: one wave per heavy pixel of the pass sums the pixel's units up.  A wave looks at 64 units at a
+// time and takes the pixels whose first unit is among them.  No scene access.
+template <typename R>
+__global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *__restrict__ out, unsigned long long *__restrict__ stats,
+                                                    uint32_t *__restrict__ wk_hdr, DWorkItem<R> *__restrict__ wk_heavy, uint32_t *__restrict__ wk_final,
+                                                    uint32_t *__restrict__ wk_unit_pixel, const DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap,
+                                                    uint32_t wk_unit_cap, int pass) {
+    Stats st;
+    stats_zero(st);
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_units = min(wk_hdr[WK_UNIT_COUNT + pass], wk_unit_cap);
+    const uint32_t *units = wk_unit_pixel + (size_t)(pass & 1) * wk_unit_cap;
+    for (uint32_t u0 = blockIdx.x * 64u; u0 < n_units; u0 += gridDim.x * 64u) { // (n_units <= 2^30: no wrap)
+        const uint32_t u = u0 + (uint32_t)lane;
+        const uint32_t p = u < n_units ? units[u] : 0xFFFFFFFFu;
+        const uint32_t prev = (u > 0 && u < n_units) ? units[u - 1] : 0xFFFFFFFFu;
+        unsigned long long firsts = __ballot(p < wk_cap && (u == 0 || prev != p)); // (p >= cap: nobody's unit)
+        while (firsts) {
+            const int i = __ffsll((long long)firsts) - 1;
+            firsts &= firsts - 1ull;
+            sum_up_units<R>(cam, out, wk_hdr, wk_heavy, wk_final, wk_unit_pixel, wk_chunks, wk_unit_cap, __shfl(p, i, 64), pass, st, lane);
+        }
+    }
+    flush_stats(st, stats);
+}
+
+// Popping work.  One counter for the whole device serialises its pops (about 12 ns each: at one unit per pop the
+// soft-shadow scene's cheap units spent 3/4 of their time waiting for it).  So every list is cut into POP_LISTS
+// sublists, each with its own counter in its own cache line; a wave starts at the sublist its index names and moves
+// on when one is empty; and a pop takes several items while the sublist is long and single ones near its end, so that
+// the launch ends evenly.  Counters only grow and a wave leaves a sublist for good: every wave runs out of lists.
+constexpr uint32_t POP_LISTS = 16;
+enum { POP_LIGHT = 0, POP_HEAVY = 1, POP_FINAL = 2, POP_UNITS = 3 /* + pass */, POP_QUEUES = 3 + 8 };
+static_assert((64 + POP_QUEUES * POP_LISTS * 32) * 4 <= WORK_HEADER_BYTES, "pop counters fit the header");
+struct Popper {
+    uint32_t list, done, seen; // the sublist this wave is at, how many it has left behind, the last head it saw there
+};
+__device__ __forceinline__ void pop_begin(Popper &pp) { pp.list = blockIdx.x % POP_LISTS; pp.done = 0; pp.seen = 0; }
+// Takes up to `most` granules of `granule` items from list `queue` of `n` items: true with [first, first + count).
+__device__ __forceinline__ bool pop(uint32_t *__restrict__ hdr, int queue, uint32_t n, uint32_t granule, uint32_t most, Popper &pp, uint32_t &first,
+                                    uint32_t &count, int lane) {
+    while (pp.done < POP_LISTS) {
+        const uint32_t lo = (uint32_t)(((unsigned long long)n * pp.list) / POP_LISTS), hi = (uint32_t)(((unsigned long long)n * (pp.list + 1u)) / POP_LISTS);
+        const uint32_t len = hi - lo, left = len > pp.seen ? len - pp.seen : 0u;
+        const uint32_t take = granule * min(most, max(1u, left / (granule * (gridDim.x / POP_LISTS * 8u + 1u))));
+        uint32_t b = len;
+        if (len) {
+            if (lane == 0) b = atomicAdd(hdr + 64 + ((uint32_t)queue * POP_LISTS + pp.list) * 32u, take);
+            b = __shfl(b, 0, 64);
+        }
+        if (b < len) {
+            pp.seen = b + take;
+            first = lo + b; count = min(take, len - b);
+            return true;
+        }
+        ++pp.done; pp.list = (pp.list + 1u) % POP_LISTS; pp.seen = 0;
+    }
+    return false;
+}
+
+// Camera::multisample's open-ended loop (camera.rs:290-299) for the pixels render_kernel queued.  Three kernels share
+// it, launched on the stream as  resample(pass 0), { units(pass), sum_up(pass) } for pass 1 .. RTMI_SPEC_PASSES,
+// resample(last).  Every launch is a grid of persistent waves that pop work until their lists - all fixed before the
+// launch - are empty, so every wave reaches the exit.
+//   resample_kernel, pass 0: the sequential loop.  First the heavy queue, one pixel per wave, 64 samples per round, then
+//     the light queue, RTMI_LIGHT_BATCH pixels per wave: a group of G lanes computes a pixel's next G samples at once
+//     (counter RNG: sample s of a pixel does not depend on who computes it); a prefix sum over the group in sample
+//     order then finds the first sample count at which the reference's loop would have stopped.  A pixel that has
+//     shown (with 64 or more samples behind its variance) that it needs RTMI_SPEC_MIN_UNITS more rounds or more is
+//     PROMOTED instead: its sums go to the heavy table and the rounds it is predicted to need become units of pass 1.
+//   units_kernel: a unit is 64 consecutive samples of one promoted pixel, one per lane, left in a DChunk for
+//     sum_up_kernel, which hands pixels that are still open to the next pass.  A pixel's thousands of samples thus
+//     spread over the whole GPU instead of running 64 at a time on one wave.
+//   resample_kernel, last launch (pass < 0): the sequential loop for the promoted pixels still open after the last pass.
+// A pixel's samples are always summed in rounds of 64 (light: RTMI_LIGHT_ROUNDS rounds of 64 / RTMI_LIGHT_BATCH first)
+// counted from its own first-pass count, whoever computes them and however many were computed ahead: the image does
+// not depend on queue order, sharding, promotion or the prediction, bit for bit.
 template <typename R, bool TREE>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
-                                                      const DWorkItem<R> *__restrict__ wk_light, const DWorkItem<R> *__restrict__ wk_heavy,
-                                                      uint32_t wk_cap) {
-    struct { uint32_t *hdr; const DWorkItem<R> *light, *heavy; uint32_t cap; } wk = {wk_hdr, wk_light, wk_heavy, wk_cap};
+                                                      const DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
+                                                      uint32_t *__restrict__ wk_final, uint32_t *__restrict__ wk_unit_pixel, uint32_t wk_cap,
+                                                      uint32_t wk_unit_cap, int pass) {
     Stats st;
     stats_zero(st);
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
     const int lane = threadIdx.x & 63;
-    const uint32_t n_heavy = min(wk.hdr[WK_HEAVY_COUNT], wk.cap), n_light = min(wk.hdr[WK_LIGHT_COUNT], wk.cap);
-    bool heavy_left = n_heavy > 0;
+    const uint32_t n_heavy = min(wk_hdr[WK_HEAVY_COUNT], wk_cap); // (fixed by render_kernel)
+    const uint32_t n_light = pass == 0 ? min(wk_hdr[WK_LIGHT_COUNT], wk_cap) : 0u;
+    // the heavy pixels of the sequential loop: the first pass's in pass 0, the leftovers in the last launch
+    const uint32_t n_seq = pass == 0 ? n_heavy : min(wk_hdr[WK_FINAL_COUNT], wk_cap);
+    const bool promote = pass == 0 && RTMI_SPEC_PASSES > 0;
+    // Promotion shortens the end of this launch (no pixel runs its thousands of samples alone) at the price of the unit
+    // passes' own launches and ends: worth it only for pixels that would outlast the queue, so the bar rises with the
+    // jobs each wave has to do anyway (headline frame: 55 jobs per wave, nothing is promoted; its 1/8 shard: 7,
+    // every pixel predicted to need RTMI_SPEC_MIN_UNITS rounds is).  The image does not depend on it.
+    const uint32_t min_units = max((uint32_t)RTMI_SPEC_MIN_UNITS, (n_heavy + n_light / (uint32_t)RTMI_LIGHT_BATCH) / (gridDim.x * (uint32_t)RTMI_SPEC_LOAD_DIV));
+    const uint32_t none = 0xFFFFFFFFu;
+    // (what the wave knows about its pops lives in LDS: nothing of it is wanted in registers across a sample)
+    __shared__ Popper seq_pop, light_pop;
+    __shared__ uint32_t popped[4]; // first item and number of items popped and not begun yet, 1 if they are heavy, 1 while the heavy list lasts
+    pop_begin(seq_pop); pop_begin(light_pop);
+    popped[0] = 0; popped[1] = 0; popped[2] = 0; popped[3] = n_seq > 0;
+    __syncthreads();
     for (;;) {
-        // ---- pop a batch ------------------------------------------------------------------------------------
+        // ---- take a batch (the longest kind first) ----------------------------------------------------------------
+        uint32_t got = popped[0], got_n = popped[1];
+        bool got_heavy = popped[2] != 0;
+        if (got_n == 0) {
+            if (popped[3] && pop(wk_hdr, pass == 0 ? POP_HEAVY : POP_FINAL, n_seq, 1u, 1u, seq_pop, got, got_n, lane)) got_heavy = true;
+            else {
+                popped[3] = 0;
+                if (!pop(wk_hdr, POP_LIGHT, n_light, (uint32_t)RTMI_LIGHT_BATCH, (uint32_t)RTMI_LIGHT_POP, light_pop, got, got_n, lane)) break;
+                got_heavy = false;
+            }
+        }
         const DWorkItem<R> *items = nullptr;
         int P = 0;
-        bool heavy_batch = false;
-        if (heavy_left) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&wk.hdr[WK_HEAVY_HEAD], 1u);
-            b = __shfl(b, 0, 64);
-            if (b < n_heavy) { items = wk.heavy + b; P = 1; heavy_batch = true; }
-            else heavy_left = false;
+        const bool heavy_batch = got_heavy;
+        uint32_t slot = none; // the pixel's place in the heavy table, if it has one
+        if (heavy_batch) {
+            const uint32_t p = pass == 0 ? got : wk_final[got];
+            items = wk_heavy + p; P = 1;
+            if (lane == 0) slot = p;
+        } else {
+            items = wk_light + got;
+            P = (int)min((uint32_t)RTMI_LIGHT_BATCH, got_n);
         }
-        if (!P) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&wk.hdr[WK_LIGHT_HEAD], (uint32_t)RTMI_LIGHT_BATCH);
-            b = __shfl(b, 0, 64);
-            if (b >= n_light) break;
-            items = wk.light + b;
-            P = (int)min((uint32_t)RTMI_LIGHT_BATCH, n_light - b);
-        }
-        const bool valid = lane < P;
+        popped[0] = got + (uint32_t)P; popped[1] = got_n - (uint32_t)P; popped[2] = got_heavy;
+        bool valid = lane < P;
         V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
         uint32_t cnt = 0;
         int px = 0, py = 0, out_row = 0;
@@ -199,11 +418,28 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
         }
         // ---- rounds -----------------------------------------------------------------------------------------
         // The chunking of a pixel's samples depends on that pixel alone (never on its neighbours in the batch or on
-        // the order of the queue), so its sums - and with them the image - are reproducible bit for bit:
-        // heavy pixels take 64 samples per round; light pixels RTMI_LIGHT_ROUNDS rounds of 64 / RTMI_LIGHT_BATCH, then 64
-        // per round, one pixel after the other.
+        // the order of the queue): heavy pixels take 64 samples per round; light pixels RTMI_LIGHT_ROUNDS rounds of
+        // 64 / RTMI_LIGHT_BATCH, then 64 per round, one pixel after the other.
         for (int round = 0;; ++round) {
-            const bool act = valid && need_more(cam, sum, sos, (R)cnt, cnt);
+            bool act = valid && need_more(cam, sum, sos, (R)cnt, cnt);
+            if (promote && act && round >= (heavy_batch ? 1 : RTMI_LIGHT_ROUNDS)) {
+                // (from here on the pixel's rounds are 64 samples wide, as its units will be)
+                const uint32_t n = predict_units(cam, sum, sos, cnt);
+                if (n >= min_units) {
+                    if (slot == none) { // a light pixel: heavy slots from the top of the table
+                        const uint32_t k = atomicAdd(&wk_hdr[WK_PROMO_COUNT], 1u);
+                        if (k < wk_cap - n_heavy) slot = wk_cap - 1u - k;
+                    }
+                    if (slot != none) {
+                        DWorkItem<R> *q = wk_heavy + slot;
+                        q->px = (uint32_t)px; q->py = (uint32_t)py; q->out_row = (uint32_t)out_row; q->cnt = cnt;
+                        q->sum[0] = sum.x; q->sum[1] = sum.y; q->sum[2] = sum.z;
+                        q->sos[0] = sos.x; q->sos[1] = sos.y; q->sos[2] = sos.z;
+                        push_heavy<R>(wk_hdr, wk_heavy, wk_final, wk_unit_pixel, wk_unit_cap, slot, n, 1);
+                        valid = false; act = false;
+                    } // else: the table is full and the pixel stays here (slow, still exact)
+                }
+            }
             const unsigned long long mask = __ballot(act);
             if (mask == 0) break;
             const bool wide = heavy_batch || round >= RTMI_LIGHT_ROUNDS;
@@ -220,16 +456,9 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
             Stats ls;
             stats_zero(ls);
             if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE>(sc, cam, rng, ls, ox, oy, s);
-            // inclusive prefix sums over the group, in sample order (the association depends on j only)
-            V3<R> ps = c, pq = had(c, c);
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                if (off < G) {
-                    V3<R> a = {__shfl_up(ps.x, off, 64), __shfl_up(ps.y, off, 64), __shfl_up(ps.z, off, 64)};
-                    V3<R> b = {__shfl_up(pq.x, off, 64), __shfl_up(pq.y, off, 64), __shfl_up(pq.z, off, 64)};
-                    if (j >= off) { ps = ps + a; pq = pq + b; }
-                }
-            }
+            // inclusive prefix sums over the group, in sample order
+            V3<R> ps = c, pq = squares(c);
+            group_prefix(ps, pq, G, j);
             const V3<R> sj = sum0 + ps, qj = sos0 + pq;
             const uint32_t cntj = cnt0 + (uint32_t)j + 1u;
             const bool stop = has && !need_more(cam, sj, qj, (R)cntj, cntj);
@@ -253,6 +482,55 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
         }
     }
     flush_stats(st, stats);
+}
+
+// The units of pass `pass` (see resample_kernel): each wave pops batches of units, takes every unit's 64 samples and
+// leaves colours and counters in the unit's DChunk.
+constexpr int UNIT_BATCH_MAX = 16;
+template <typename R, bool TREE>
+__global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
+                                                   const DWorkItem<R> *__restrict__ wk_heavy, const uint32_t *__restrict__ wk_unit_pixel,
+                                                   DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass) {
+    Rng rng;
+    rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_units = min(wk_hdr[WK_UNIT_COUNT + pass], wk_unit_cap);
+    const uint32_t *units = wk_unit_pixel + (size_t)(pass & 1) * wk_unit_cap;
+    // The batch's pixels are fetched by one lane each and handed out by lane reads.  (No LDS, no barrier: a fence in
+    // this loop would stop the compiler from proving that the scene is never written here, and with that proof go the
+    // scalar loads of the scene records.)
+    Popper pp;
+    pop_begin(pp);
+    for (;;) {
+        uint32_t u0 = 0, nb = 0;
+        if (!pop(wk_hdr, POP_UNITS + pass, n_units, 1u, (uint32_t)UNIT_BATCH_MAX, pp, u0, nb, lane)) break;
+        uint32_t bp = 0xFFFFFFFFu, bx = 0, by = 0, bc = 0;
+        if ((uint32_t)lane < nb) {
+            bp = units[u0 + (uint32_t)lane];
+            if (bp < wk_cap) {
+                const DWorkItem<R> *q = wk_heavy + bp;
+                bx = q->px; by = q->py;
+                bc = q->cnt + (u0 + (uint32_t)lane - q->unit_base) * 64u; // first sample of the unit
+            }
+        }
+#pragma unroll 1
+        for (uint32_t i = 0; i < nb; ++i) {
+            if (__shfl(bp, (int)i, 64) >= wk_cap) continue; // a unit nobody owns (the list overflowed)
+            const int px = (int)__shfl(bx, (int)i, 64), py = (int)__shfl(by, (int)i, 64);
+            const uint32_t s = __shfl(bc, (int)i, 64) + (uint32_t)lane;
+            V3<R> c = mk<R>(0, 0, 0);
+            Stats ls;
+            stats_zero(ls);
+            if (!(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE>(sc, cam, rng, ls, px, py, s);
+            DChunk<R> *ch = wk_chunks + (u0 + i);
+            ch->col[0][lane] = c.x; ch->col[1][lane] = c.y; ch->col[2][lane] = c.z;
+            ch->st[0][lane] = (ls.c[RTMI_STAT_PRIMARY] & 0xFFu) | ((ls.c[RTMI_STAT_SAMPLES] & 0xFFu) << 8) | (min(ls.c[RTMI_STAT_OVERFLOW], 0xFFFFu) << 16);
+            ch->st[1][lane] = ls.c[RTMI_STAT_REFLECTION]; ch->st[2][lane] = ls.c[RTMI_STAT_REFRACTION];
+            ch->st[3][lane] = ls.c[RTMI_STAT_SHADOW]; ch->st[4][lane] = ls.c[RTMI_STAT_LEAF_TESTS];
+            ch->st[5][lane] = ls.c[RTMI_STAT_NODE_VISITS]; ch->st[6][lane] = ls.c[RTMI_STAT_AABB_TESTS];
+            ch->st[7][lane] = (uint32_t)ls.flops;
+        }
+    }
 }
 
 #endif // RTMI_HOST_EMUL
@@ -331,8 +609,18 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
     if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     if (!wk.hdr || grid_resample <= 0) return;
-    if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
-    else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    for (int l = 0; l <= RTMI_SPEC_PASSES + 1; ++l) {
+        const int pass = l <= RTMI_SPEC_PASSES ? l : -1;
+        if (pass < 0 && RTMI_SPEC_PASSES == 0) break;
+        if (pass > 0) {
+            if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            else hipLaunchKernelGGL((units_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            hipLaunchKernelGGL(sum_up_kernel<RTMI_REAL>, dim3(grid_resample), dim3(64), 0, st, cam, out, stats, wk.hdr, wk.heavy, wk.final_idx, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+        } else {
+            if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass);
+            else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass);
+        }
+    }
 }
 #else
 template <>

@@ -3,16 +3,45 @@
 #include "rtmi_device.hpp"
 
 namespace rtmi_dev {
-// Work queues of the adaptive second pass (resample_kernel).  `work` is WORK_HEADER_BYTES of counters followed by two
-// equal arrays of DWorkItem<R>; the header must be zero when render_kernel starts.  work == nullptr: no second pass,
-// every lane finishes its own pixel.
-constexpr size_t WORK_HEADER_BYTES = 256;
-enum { WK_LIGHT_COUNT = 0, WK_HEAVY_COUNT = 1, WK_LIGHT_HEAD = 2, WK_HEAVY_HEAD = 3 };
+// Work memory of the adaptive second pass (resample_kernel, sum_up_kernel).  `work` is WORK_HEADER_BYTES of counters
+// (zero when render_kernel starts) followed by
+//   light[cap], heavy[cap]   queued pixels with their running sums, by predicted need (render_kernel fills both from
+//                            the bottom; light pixels promoted later take heavy slots from the top)
+//   final_idx[cap]           promoted pixels left to the sequential loop after the last pass
+//   unit_pixel[2][unit_cap]  per pass (ping-pong): the heavy pixel each 64-sample unit belongs to
+//   chunks[unit_cap]         the samples a unit took, one record per unit, consumed by the pass's sum_up_kernel
+// work == nullptr: no second pass, every lane finishes its own pixel.
+constexpr size_t WORK_HEADER_BYTES = 32768; // 64 counters, then the unit passes' pop counters, one per cache line
+#ifndef RTMI_SPEC_PASSES
+#define RTMI_SPEC_PASSES 3 // launches that take the promoted pixels' samples as units, before the sequential loop gets what is left (0..7)
+#endif
+#ifndef RTMI_SPEC_MIN_UNITS
+#define RTMI_SPEC_MIN_UNITS 4 // a pixel in the sequential loop is promoted when it is predicted to need at least this many more rounds
+#endif
+#ifndef RTMI_SPEC_LOAD_DIV
+#define RTMI_SPEC_LOAD_DIV 1 // ... and at least 1 / this of the jobs (heavy pixels + light batches) the pass has per wave
+#endif
+#ifndef RTMI_SPEC_MARGIN
+#define RTMI_SPEC_MARGIN 1.0 // units are given for this multiple of the predicted need
+#endif
+#ifndef RTMI_SPEC_MAX
+#define RTMI_SPEC_MAX 64 // most units a pixel is given in one pass
+#endif
+constexpr int WK_MAX_LAUNCHES = 9; // RTMI_SPEC_PASSES + 2
+enum {
+    WK_LIGHT_COUNT = 0, WK_HEAVY_COUNT = 1, WK_FINAL_COUNT = 2, WK_FINAL_HEAD = 3, WK_HEAVY_HEAD = 4, WK_PROMO_COUNT = 5, WK_LIGHT_HEAD = 6,
+    WK_UNIT_COUNT = 8   // + pass (1 .. RTMI_SPEC_PASSES)
+};
+static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
 #ifndef RTMI_LIGHT_NEED
 #define RTMI_LIGHT_NEED 192 // predicted further samples up to which a pixel goes to the light queue
 #endif
 #ifndef RTMI_LIGHT_BATCH
 #define RTMI_LIGHT_BATCH 2  // light pixels per wave (a power of two): 32 lanes per pixel
+#endif
+#ifndef RTMI_LIGHT_POP
+#define RTMI_LIGHT_POP 1 // most light batches a wave pops at once (neighbours in the queue are neighbours in the image and cost
+// alike: 8 at once left the waves that met the glass spheres 0.7 ms behind the others on the headline frame)
 #endif
 #ifndef RTMI_LIGHT_ROUNDS
 #define RTMI_LIGHT_ROUNDS 6 // rounds a light batch runs 32 lanes per pixel before its leftovers get the whole wave
@@ -22,19 +51,40 @@ enum { WK_LIGHT_COUNT = 0, WK_HEAVY_COUNT = 1, WK_LIGHT_HEAD = 2, WK_HEAVY_HEAD 
 template <typename R> struct DWorkItem {
     uint32_t px, py, out_row, cnt; // global pixel, row in this rank's compact buffer, samples taken so far
     R sum[3], sos[3];              // running sum and sum of squares (camera.rs:277-279)
+    uint32_t unit_base, n_chunks;  // heavy pixels: this pass's units are [unit_base, unit_base + n_chunks)
+};
+// what one unit (64 consecutive samples of one pixel, one per lane) leaves for the wave that sums the pixel up
+constexpr int CHUNK_STAT_WORDS = 8;
+template <typename R> struct DChunk {
+    R col[3][64];
+    uint32_t st[CHUNK_STAT_WORDS][64]; // primary | samples << 8 | overflow << 16, reflection, refraction, shadow, leaf tests, node visits, slab tests, flops
 };
 template <typename R> struct DWork {
     uint32_t *hdr;
     DWorkItem<R> *light, *heavy;
-    uint32_t cap; // items per queue
+    uint32_t *final_idx, *unit_pixel;
+    DChunk<R> *chunks;
+    uint32_t cap;      // items per queue
+    uint32_t unit_cap; // units per pass
 };
 template <typename R> inline DWork<R> make_work(void *work, size_t bytes) {
-    DWork<R> w = {nullptr, nullptr, nullptr, 0};
-    if (!work || bytes < WORK_HEADER_BYTES + 2 * sizeof(DWorkItem<R>)) return w;
-    w.hdr = (uint32_t *)work;
-    w.cap = (uint32_t)((bytes - WORK_HEADER_BYTES) / (2 * sizeof(DWorkItem<R>)));
-    w.light = (DWorkItem<R> *)((char *)work + WORK_HEADER_BYTES);
-    w.heavy = w.light + w.cap;
+    DWork<R> w = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (!work || bytes < (1u << 20)) return w;
+    // half of the memory for the two queues, the rest (less final_idx) for the units
+    size_t cap = bytes / 2 / (2 * sizeof(DWorkItem<R>));
+    if (cap > 0x7FFFFFFFu) cap = 0x7FFFFFFFu;
+    char *p = (char *)work;
+    w.hdr = (uint32_t *)p; p += WORK_HEADER_BYTES;
+    w.light = (DWorkItem<R> *)p; p += cap * sizeof(DWorkItem<R>);
+    w.heavy = (DWorkItem<R> *)p; p += cap * sizeof(DWorkItem<R>);
+    w.final_idx = (uint32_t *)p; p += cap * sizeof(uint32_t);
+    p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    size_t left = (size_t)((char *)work + bytes - p);
+    size_t unit_cap = left / (sizeof(DChunk<R>) + 2 * sizeof(uint32_t) + 1); // (+1: room for the alignment below)
+    if (unit_cap > 0x3FFFFFFFu) unit_cap = 0x3FFFFFFFu;
+    w.chunks = (DChunk<R> *)p; p += unit_cap * sizeof(DChunk<R>);
+    w.unit_pixel = (uint32_t *)p;
+    w.cap = (uint32_t)cap; w.unit_cap = (uint32_t)unit_cap;
     return w;
 }
 

@@ -13,16 +13,20 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD 
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
   if [ "$SETS" = "mem" ] && [ $i -lt 4 ]; then continue; fi
+  if [ "$SETS" = "sq" ] && [ $i -gt 2 ]; then continue; fi
   (cd /tmp && timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $R/$out/pass$i -- python3 $R/bench.py $args --no-cpu-baseline > $R/$out/pass$i.json 2> $R/$out/pass$i.err) || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections
 for d in sorted(glob.glob("$R/$out/pass*/")):
-    agg = collections.defaultdict(lambda: [0.0, 0])
+    agg = collections.defaultdict(float)
+    frames = 0
+    seen = set()
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            kn = "render_kernel" if "render_kernel" in row["Kernel_Name"] else "resample_kernel" if "resample_kernel" in row["Kernel_Name"] else None
+            kn = next((k for k in ("render_kernel", "resample_kernel", "units_kernel", "sum_up_kernel") if k in row["Kernel_Name"]), None)
             if kn is None: continue
-            a = agg[(kn, row["Counter_Name"])]; a[0] += float(row["Counter_Value"]); a[1] += 1
-    for (kn, k), (v, n) in sorted(agg.items()): print(d.split("/")[-2], kn, k, "per-launch %.6g" % (v / n), "launches", n)
+            agg[(kn, row["Counter_Name"])] += float(row["Counter_Value"])
+            if kn == "render_kernel" and row["Dispatch_Id"] not in seen: seen.add(row["Dispatch_Id"]); frames += 1
+    for (kn, k), v in sorted(agg.items()): print(d.split("/")[-2], kn, k, "per-frame %.6g" % (v / max(frames, 1)), "frames", frames)
 PY
