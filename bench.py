@@ -8,8 +8,11 @@ Workload (BASELINE.json configs[1]): the reference's chapter-11a reflection/refr
     python bench.py --gpus N --steps K --warmup W            (N > 1: one process per GPU under torch.distributed.run)
 
 N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
-gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py); the render runs on its own
-HIP stream, double-buffered, so frame i+1 renders while frame i is gathered.  Rank 0 prints ONE JSON line.
+gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default
+3) frames are in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside
+the library): the ends of one frame's kernels - a few waves finishing the deepest pixels - and its gather overlap
+the next frame's first pass.  Every frame is rendered completely and gathered inside the timed region; F = 1 runs
+the frames strictly one after the other.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -27,8 +30,10 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 C
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
+                    help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device)")
     ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -118,17 +123,20 @@ def main():
     from raytracing_amd import tiles
     gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=xdev, dtype=torch.uint8 if a.gather == "rgb8" else torch.float32)
     assert gather.rows == abi.rank_rows(v, rank, world_size, a.tile_rows)
-    bufs = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.float32, device=dev) for _ in range(2)]  # double-buffered
-    bufs8 = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if a.gather == "rgb8" else None
+    F = a.frames_in_flight
+    NB = max(F, 2)  # buffers: at least two, so that frame i+1 renders while frame i is gathered even with one stream
+    bufs = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.float32, device=dev) for _ in range(NB)]
+    bufs8 = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.uint8, device=dev) for _ in range(NB)] if a.gather == "rgb8" else None
     stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
-    render_stream = torch.cuda.Stream(device=dev)
-    ev_rendered = [torch.cuda.Event(), torch.cuda.Event()]
-    ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+    render_streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    ev_rendered = [torch.cuda.Event() for _ in range(NB)]
+    ev_free = [torch.cuda.Event() for _ in range(NB)]
     frames = {"n": 0, "last": None}
 
     def step(timed_events=None):
         """One frame: render this rank's row tiles (own stream), then gather the rows to rank 0 and assemble the canvas."""
-        b = frames["n"] & 1
+        b = frames["n"] % NB
+        render_stream = render_streams[frames["n"] % F]
         frames["n"] += 1
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(render_stream):
@@ -163,7 +171,19 @@ def main():
         step(pairs[i])
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = [p[0].elapsed_time(p[1]) for p in pairs]
+    # per launch: the span of the timed region on the render streams / launches (with F > 1 the launches overlap, so a
+    # single launch's own start-to-end time says little), and afterwards the same call alone on an idle GPU
+    span_ms = max(pairs[0][0].elapsed_time(p[1]) for p in pairs)
+    serial = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(render_streams[0]):
+            e0.record(render_streams[0])
+            abi.render_device(scene, cam, opts, bufs[0], None, render_streams[0].cuda_stream)
+            e1.record(render_streams[0])
+        torch.cuda.synchronize()
+        serial.append(e0.elapsed_time(e1))
+    serial_ms = sum(serial) / len(serial)
 
     t = torch.tensor([dt], dtype=torch.float64, device=xdev)
     tot = stats.clone().to(xdev)
@@ -191,7 +211,7 @@ def main():
         if not same:
             sys.exit(3)
     if rank == 0:
-        k_ms = sum(kernel_ms) / len(kernel_ms)
+        k_ms = span_ms / a.steps
         flops_launch = float(st_local[abi.STAT_NAMES.index("flops")]) / a.steps  # this rank's launch
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
         traffic = None
@@ -217,18 +237,23 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_name(a), "scene": a.scene, "max_depth": int(world.max_reflection_depth),
                        "seed": a.seed, "sharding": ("8-row tiles round-robin, %s gather of %s rows to rank 0" % (a.backend, a.gather)) if world_size > 1 else "none",
+                       "frames_in_flight": F,
                        "rays_per_step": rays // a.steps, "samples_per_step": S["samples"] // a.steps,
                        "discarded_samples_per_step": S["discarded"] // a.steps,
                        "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "render_kernel<%s> + resample_kernel<%s> (the two launches of one rtmi_render_device call; "
-                                   "rocprofv3 averages: profiles/)" % (a.precision, a.precision), "kernel_ms": k_ms,
+                         "kernel": "render_kernel<%s> + resample_kernel<%s> + units_kernel<%s> + sum_up_kernel<%s> (the launches of one "
+                                   "rtmi_render_device call; rocprofv3 averages: profiles/)" % ((a.precision,) * 4),
+                         "kernel_ms": k_ms, "kernel_ms_alone": serial_ms,
+                         "frac_alone": flops_launch / (serial_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                          "algorithmic_flops_per_launch": flops_launch,
                          "note": "FP32 vector (VALU) roofline, no MFMA on this path; algorithmic FLOPs = reference "
-                                 "arithmetic per event (DESIGN.md 'Roofline and accounting'), rank 0's launch; kernel_ms = HIP "
-                                 "events on the render stream around the call; traffic = HBM bytes per call from PMC passes "
-                                 "(profiles/traffic.json)"},
+                                 "arithmetic per event (DESIGN.md 'Roofline and accounting'), rank 0's launch; kernel_ms = span of "
+                                 "the timed region between HIP events on the render streams / calls (calls of frames in flight "
+                                 "overlap); kernel_ms_alone / frac_alone = one call alone on the idle GPU, HIP events around it: the "
+                                 "figure rocprofv3's per-kernel averages of a --frames-in-flight 1 run add up to; traffic = HBM "
+                                 "bytes per call from PMC passes (profiles/traffic.json)"},
         }
         if not a.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, a, scenes)
