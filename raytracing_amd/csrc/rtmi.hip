@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -60,7 +61,17 @@ template <typename R> struct DeviceArrays {
 // A stream is bound to a slot the first time it renders; work on one stream is ordered, so one slot per stream is
 // race-free, and renders on different streams use different slots.
 constexpr int WORK_SLOTS = 4;
-constexpr size_t WORK_BYTES = (size_t)2 << 30; // 2 x 9.5 M queued pixels (f32: a whole 3840x2160 frame per queue) + 330 k units of 64 samples; 8 GB of 288 GB per device
+constexpr size_t WORK_BYTES = (size_t)2 << 30; // 2 x 11 M queued pixels (f32: a whole 3840x2160 frame per queue) + 370 k units of 64 samples; 8 GB of 288 GB per device
+// RTMI_WORK_MB (read once per process): the slot size in MiB instead, for tests that want queues, unit lists and the
+// heavy table to overflow (every overflow path is exact, only slower)
+static size_t work_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("RTMI_WORK_MB");
+        const long mb = e ? atol(e) : 0;
+        return mb >= 2 && mb <= 65536 ? (size_t)mb << 20 : WORK_BYTES;
+    }();
+    return v;
+}
 constexpr int MAX_DEVICES = 64;
 struct WorkPool {
     int refs = 0;
@@ -77,7 +88,7 @@ static int pool_acquire(int dev) {
     WorkPool &p = g_pool[dev];
     if (p.refs == 0) {
         for (int i = 0; i < WORK_SLOTS; ++i) {
-            hipError_t e = hipMalloc(&p.buf[i], WORK_BYTES);
+            hipError_t e = hipMalloc(&p.buf[i], work_bytes());
             if (e != hipSuccess) {
                 for (int k = 0; k < i; ++k) { (void)hipFree(p.buf[k]); p.buf[k] = nullptr; }
                 p.buf[i] = nullptr;
@@ -622,8 +633,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
         HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st));
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
-    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, WORK_BYTES);
-    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, WORK_BYTES);
+    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, work_bytes());
+    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, work_bytes());
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }

@@ -1,0 +1,68 @@
+"""The adaptive second pass with a work-queue slot far too small for the frame (RTMI_WORK_MB).  While the two queues
+still hold every unconverged pixel, unit lists and the heavy table may overflow as they like: the image and the ray
+counters stay what they are with room to spare, bit for bit (the chunking of a pixel's samples never depends on who
+computes them).  When the queues themselves overflow, the lanes left without a slot finish their pixels alone, sample
+by sample like the reference: the same stopping rule on sums added in another order, so the frame agrees closely
+but not bit for bit."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import torch
+from raytracing_amd import abi, scenes
+out = {}
+for name, build, h, v in (("ch11a", scenes.chapter11a, 320, 180), ("soft", scenes.soft_shadow, 160, 90), ("ch11a_big", scenes.chapter11a, 1280, 720)):
+    world, cam = build(h, v)
+    sc = abi.Scene(world)
+    buf = torch.zeros((v, h, 3), dtype=torch.float32, device="cuda")
+    st = torch.zeros(abi.N_STATS, dtype=torch.int64, device="cuda")
+    abi.render_device(sc, cam, abi.make_opts(seed=7), buf, st, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    s = st.cpu().tolist()
+    img = buf.cpu().numpy()
+    out[name] = {"sha": hashlib.sha256(img.tobytes()).hexdigest(), "stats": s[:abi.STAT_NAMES.index("discarded")],
+                 "mean": float(img.mean()), "coarse": img.reshape(v // 10, 10, h // 10, 10, 3).mean(axis=(1, 3)).round(4).tolist()}
+    sc.close()
+print(json.dumps(out))
+""" % ROOT
+
+
+def _render(work_mb):
+    env = dict(os.environ)
+    env.pop("RTMI_WORK_MB", None)
+    if work_mb:
+        env["RTMI_WORK_MB"] = str(work_mb)
+    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_small_work_slots_change_nothing():
+    full = _render(0)
+    # 2 MiB: 10922 pixels per queue, 360 units per pass.  The small frames' queues fit; their unit lists do not.
+    small = _render(2)
+    for scene in ("ch11a", "soft"):
+        assert small[scene]["sha"] == full[scene]["sha"], scene
+        assert small[scene]["stats"] == full[scene]["stats"], scene
+    # ... the 1280x720 frame queues three times that many pixels: the rest are finished by their first-pass lanes
+    import numpy as np
+    a, b = np.array(small["ch11a_big"]["coarse"]), np.array(full["ch11a_big"]["coarse"])
+    assert np.abs(a - b).max() < 0.02
+    sa, sb = small["ch11a_big"]["stats"], full["ch11a_big"]["stats"]
+    i = 4  # samples
+    assert abs(sa[i] - sb[i]) < 0.01 * sb[i]
+    # 16 MiB: every queue fits again, the unit lists (2900 units) overflow on the big frame
+    mid = _render(16)
+    for scene in full:
+        assert mid[scene]["sha"] == full[scene]["sha"], scene
+        assert mid[scene]["stats"] == full[scene]["stats"], scene
