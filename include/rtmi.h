@@ -218,10 +218,11 @@ int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_r
  * and the memory (one process per GPU under torch.distributed, HIP graphs).  d_rgb_out receives
  * only the rows this rank owns, compacted in tile order: rtmi_rank_rows(...)*hsize*3 floats.
  * d_stats (may be NULL) points at RTMI_N_STATS device u64 that are ADDED to.  Allocates nothing:
- * the work queues of the adaptive second pass come from a per-device pool created with the first
- * scene of the device (4 slots of 512 MB, one per stream that renders).  Work on one stream is
- * ordered; a fifth distinct stream on a device is refused with RTMI_ERR_UNSUPPORTED.  Enqueues a
- * 256-byte memset and one or two kernels (camera.rs:273-291 first, 290-299 second).               */
+ * the work memory of the adaptive second pass comes from a per-device pool created with the first
+ * scene of the device (4 slots of 2 GB, one per stream that renders).  Work on one stream is
+ * ordered, calls on different streams overlap on the GPU; a fifth distinct stream on a device is
+ * refused with RTMI_ERR_UNSUPPORTED.  Enqueues a 32 KB memset and one to nine kernels
+ * (camera.rs:273-291 first; 290-299 the others).                                                  */
 int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera,
                        const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
                        void *hip_stream);

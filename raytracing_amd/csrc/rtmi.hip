@@ -623,7 +623,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     DCamera<double> cam = make_camera<double>(c, o);
     unsigned long long *ds = (unsigned long long *)d_stats;
     // the open-ended part of Camera::multisample runs as a second kernel over work queues (only if it can be reached)
-    const bool open_ended = std::isfinite(c->allowed_standard_error) && !(cam.max_samples > 0 && cam.max_samples <= cam.min_samples);
+    // (with min_samples <= 1 every pixel stops at its first sample - the variance of one sample is zero - so there is nothing to queue)
+    const bool open_ended = std::isfinite(c->allowed_standard_error) && cam.min_samples > 1 && !(cam.max_samples > 0 && cam.max_samples <= cam.min_samples);
     void *work = nullptr;
     std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
     if (open_ended) {

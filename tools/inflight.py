@@ -11,7 +11,7 @@ sc = abi.Scene(world)
 rows = abi.rank_rows(V, 0, nr, 8)
 opts = abi.make_opts(rank=0, nranks=nr, tile_rows=8)
 all_streams = [torch.cuda.Stream() for _ in range(4)]
-for k in (3, 4, 3, 4):
+for k in (1, 3, 1, 3):
     streams = all_streams[:k]
     bufs = [torch.zeros((rows, H, 3), dtype=torch.float32, device="cuda") for _ in range(k)]
     for i in range(2 * k):
