@@ -608,6 +608,9 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.tiles_x = (c->hsize + 7) / 8;
     rp.local_tile_rows8 = (rows + 7) / 8;
     rp.n_tiles = rp.tiles_x * rp.local_tile_rows8;
+    rp.tile_step = 1;
+    for (uint32_t p : {7919u, 7927u, 7933u, 7937u}) // primes: coprime to n_tiles unless they divide it
+        if ((uint32_t)rp.n_tiles % p != 0) { rp.tile_step = p; break; }
     // Waves stride over the tiles.  More waves than the 12 resident per CU lets the hardware dispatcher balance uneven tiles
     // (measured on chapter-11a at 3840x2160: 96 per CU beats 32 by 11 % with 5 samples per tile visit), but each extra wave
     // costs its launch, which dominates when a tile visit is a single sample (32 per CU beats 96 by 50 % there).
@@ -634,6 +637,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
         HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st));
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
+    // (adaptive renders pop their tiles - render_kernel - so the first pass too is one resident set of persistent waves)
+    if (open_ended && RTMI_DYNAMIC_TILES) grid = std::min(rp.n_tiles, s->num_cu * 4 * RTMI_RESAMPLE_WAVES);
     if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, work_bytes());
     else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, work_bytes());
     HIP_TRY(hipGetLastError());

@@ -148,6 +148,7 @@ struct DRender {
     int32_t rank, nranks, tile_rows;
     int32_t tiles_x, local_tile_rows8; // 8-row tile rows owned by this rank
     int32_t n_tiles;
+    uint32_t tile_step; // coprime to n_tiles: the k-th tile popped is k * tile_step mod n_tiles (neighbours cost alike: scatter them)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -123,6 +123,40 @@ __device__ __forceinline__ void push_heavy(uint32_t *__restrict__ hdr, DWorkItem
     final_idx[f] = p; // f < cap: a heavy pixel comes here at most once
 }
 
+// Popping work.  One counter for the whole device serialises its pops (about 12 ns each: at one unit per pop the
+// soft-shadow scene's cheap units spent 3/4 of their time waiting for it).  So every list is cut into POP_LISTS
+// sublists, each with its own counter in its own cache line; a wave starts at the sublist its index names and moves
+// on when one is empty; and a pop takes several items while the sublist is long and single ones near its end, so that
+// the launch ends evenly.  Counters only grow and a wave leaves a sublist for good: every wave runs out of lists.
+constexpr uint32_t POP_LISTS = 16;
+enum { POP_LIGHT = 0, POP_HEAVY = 1, POP_FINAL = 2, POP_TILES = 3, POP_UNITS = 4 /* + pass */, POP_QUEUES = 4 + 8 };
+static_assert((64 + POP_QUEUES * POP_LISTS * 32) * 4 <= WORK_HEADER_BYTES, "pop counters fit the header");
+struct Popper {
+    uint32_t list, done, seen; // the sublist this wave is at, how many it has left behind, the last head it saw there
+};
+__device__ __forceinline__ void pop_begin(Popper &pp) { pp.list = blockIdx.x % POP_LISTS; pp.done = 0; pp.seen = 0; }
+// Takes up to `most` granules of `granule` items from list `queue` of `n` items: true with [first, first + count).
+__device__ __forceinline__ bool pop(uint32_t *__restrict__ hdr, int queue, uint32_t n, uint32_t granule, uint32_t most, Popper &pp, uint32_t &first,
+                                    uint32_t &count, int lane) {
+    while (pp.done < POP_LISTS) {
+        const uint32_t lo = (uint32_t)(((unsigned long long)n * pp.list) / POP_LISTS), hi = (uint32_t)(((unsigned long long)n * (pp.list + 1u)) / POP_LISTS);
+        const uint32_t len = hi - lo, left = len > pp.seen ? len - pp.seen : 0u;
+        const uint32_t take = granule * min(most, max(1u, left / (granule * (gridDim.x / POP_LISTS * 8u + 1u))));
+        uint32_t b = len;
+        if (len) {
+            if (lane == 0) b = atomicAdd(hdr + 64 + ((uint32_t)queue * POP_LISTS + pp.list) * 32u, take);
+            b = __shfl(b, 0, 64);
+        }
+        if (b < len) {
+            pp.seen = b + take;
+            first = lo + b; count = min(take, len - b);
+            return true;
+        }
+        ++pp.done; pp.list = (pp.list + 1u) % POP_LISTS; pp.seen = 0;
+    }
+    return false;
+}
+
 // Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310), first pass: one wave64 per 8x8 pixel tile,
 // waves stride over the tiles this rank owns; every pixel takes its first min_samples samples on its own lane (all 64
 // lanes busy, neighbouring rays coherent).  Pixels the reference's loop would stop at (camera.rs:290-291) are written
@@ -143,7 +177,17 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int sub = rp.tile_rows >> 3; // 8-row rows per ownership tile
-    for (int tile = blockIdx.x; tile < rp.n_tiles; tile += gridDim.x) {
+    // With work memory at hand (an adaptive render) the waves pop their tiles instead of striding over them: tiles
+    // differ by an order of magnitude, and on a small shard (an 8-GPU run) a wave's handful of tiles does not average out.
+    const bool dynamic = RTMI_DYNAMIC_TILES && wk_hdr != nullptr;
+    __shared__ Popper tile_pop;
+    if (dynamic) { pop_begin(tile_pop); __syncthreads(); }
+    for (int tile = blockIdx.x;; tile += gridDim.x) {
+        if (dynamic) {
+            uint32_t t0 = 0, t1 = 0;
+            if (!pop(wk_hdr, POP_TILES, (uint32_t)rp.n_tiles, 1u, 1u, tile_pop, t0, t1, lane)) break;
+            tile = (int)(((unsigned long long)t0 * rp.tile_step) % (uint32_t)rp.n_tiles);
+        } else if (tile >= rp.n_tiles) break;
         int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
         int lt = ltr / sub, within = ltr - lt * sub;
         int gt = lt * rp.nranks + rp.rank;
@@ -300,40 +344,6 @@ __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *
         }
     }
     flush_stats(st, stats);
-}
-
-// Popping work.  One counter for the whole device serialises its pops (about 12 ns each: at one unit per pop the
-// soft-shadow scene's cheap units spent 3/4 of their time waiting for it).  So every list is cut into POP_LISTS
-// sublists, each with its own counter in its own cache line; a wave starts at the sublist its index names and moves
-// on when one is empty; and a pop takes several items while the sublist is long and single ones near its end, so that
-// the launch ends evenly.  Counters only grow and a wave leaves a sublist for good: every wave runs out of lists.
-constexpr uint32_t POP_LISTS = 16;
-enum { POP_LIGHT = 0, POP_HEAVY = 1, POP_FINAL = 2, POP_UNITS = 3 /* + pass */, POP_QUEUES = 3 + 8 };
-static_assert((64 + POP_QUEUES * POP_LISTS * 32) * 4 <= WORK_HEADER_BYTES, "pop counters fit the header");
-struct Popper {
-    uint32_t list, done, seen; // the sublist this wave is at, how many it has left behind, the last head it saw there
-};
-__device__ __forceinline__ void pop_begin(Popper &pp) { pp.list = blockIdx.x % POP_LISTS; pp.done = 0; pp.seen = 0; }
-// Takes up to `most` granules of `granule` items from list `queue` of `n` items: true with [first, first + count).
-__device__ __forceinline__ bool pop(uint32_t *__restrict__ hdr, int queue, uint32_t n, uint32_t granule, uint32_t most, Popper &pp, uint32_t &first,
-                                    uint32_t &count, int lane) {
-    while (pp.done < POP_LISTS) {
-        const uint32_t lo = (uint32_t)(((unsigned long long)n * pp.list) / POP_LISTS), hi = (uint32_t)(((unsigned long long)n * (pp.list + 1u)) / POP_LISTS);
-        const uint32_t len = hi - lo, left = len > pp.seen ? len - pp.seen : 0u;
-        const uint32_t take = granule * min(most, max(1u, left / (granule * (gridDim.x / POP_LISTS * 8u + 1u))));
-        uint32_t b = len;
-        if (len) {
-            if (lane == 0) b = atomicAdd(hdr + 64 + ((uint32_t)queue * POP_LISTS + pp.list) * 32u, take);
-            b = __shfl(b, 0, 64);
-        }
-        if (b < len) {
-            pp.seen = b + take;
-            first = lo + b; count = min(take, len - b);
-            return true;
-        }
-        ++pp.done; pp.list = (pp.list + 1u) % POP_LISTS; pp.seen = 0;
-    }
-    return false;
 }
 
 // Camera::multisample's open-ended loop (camera.rs:290-299) for the pixels render_kernel queued.  Three kernels share
