@@ -584,14 +584,27 @@ static int check_camera(const rtmi_camera *c) {
 }
 
 #ifndef RTMI_GRID_PER_CU
-#define RTMI_GRID_PER_CU 32 // waves of the first pass per CU (they stride over the tiles) when a tile visit is short
+#define RTMI_GRID_PER_CU 32 // waves of the first pass per CU (they stride over the visits) when a visit is one sample
 #endif
 #ifndef RTMI_GRID_PER_CU_MANY
 #define RTMI_GRID_PER_CU_MANY 96 // ... and when every pixel takes several samples per visit
 #endif
+#ifndef RTMI_SPREAD_BELOW
+#define RTMI_SPREAD_BELOW 8 // a pixel's first samples go on lanes of their own when the frame has fewer 8x8 tiles than this per resident wave
+#endif
 #ifndef RTMI_RESAMPLE_WAVES
 #define RTMI_RESAMPLE_WAVES 3 // waves per SIMD of the second pass's persistent grid
 #endif
+
+// RTMI_SPREAD_BELOW in the environment (read once per process) replaces the constant: 0 = never spread, a large number =
+// always; for the tests that hold both ways of the first pass against each other
+static long spread_below() {
+    static const long v = [] {
+        const char *e = getenv("RTMI_SPREAD_BELOW");
+        return e ? atol(e) : (long)RTMI_SPREAD_BELOW;
+    }();
+    return v;
+}
 
 static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st) {
     int rank = 0, nranks = 1, tr = 8;
@@ -608,18 +621,29 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.tiles_x = (c->hsize + 7) / 8;
     rp.local_tile_rows8 = (rows + 7) / 8;
     rp.n_tiles = rp.tiles_x * rp.local_tile_rows8;
-    rp.tile_step = 1;
-    for (uint32_t p : {7919u, 7927u, 7933u, 7937u}) // primes: coprime to n_tiles unless they divide it
-        if ((uint32_t)rp.n_tiles % p != 0) { rp.tile_step = p; break; }
-    // Waves stride over the tiles.  More waves than the 12 resident per CU lets the hardware dispatcher balance uneven tiles
-    // (measured on chapter-11a at 3840x2160: 96 per CU beats 32 by 11 % with 5 samples per tile visit), but each extra wave
-    // costs its launch, which dominates when a tile visit is a single sample (32 per CU beats 96 by 50 % there).
-    const int first_samples = (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples;
-    const int per_cu = first_samples >= 4 ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU;
-    // ... and a wave that visits a single tile is mostly launch cost (one wave per tile: +25 % on the whole frame), which
-    // matters for the small per-rank frames of an 8-GPU run: at least 3 tiles per wave while that still fills the GPU.
-    int grid = std::min(rp.n_tiles, s->num_cu * per_cu);
-    grid = std::max(std::min(grid, (rp.n_tiles + 2) / 3), std::min(rp.n_tiles, s->num_cu * 12));
+    // The first pass (render_kernel) takes every pixel's first `first_samples` samples either on one lane, one after the
+    // other, or on `first_samples` lanes at once; same sums either way.  The second way makes a wave's visit one sample
+    // long instead of first_samples: that is what a small frame needs (its last visits ARE its first pass) and what a
+    // large one pays 15 % for (idle lanes when 64 is not a multiple, no gain at the end that 40 visits per wave do not
+    // give anyway).  Waves stride over the visits; more waves than the 12 resident per CU lets the hardware dispatcher
+    // balance uneven visits, but each extra wave costs its launch (measured on chapter-11a at 3840x2160: 96 per CU beats
+    // 32 by 11 % with 5 samples per visit, 32 beats 96 by 50 % with one; a wave with a single visit is mostly launch
+    // cost: at least 3 visits per wave while that still fills the GPU).
+    const int first_samples = std::max(1, (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples);
+    // The choice looks at the WHOLE frame, never at this rank's share: the two instantiations add the same samples in
+    // the same order, but the compiler fuses multiply-adds inside a sample's arithmetic differently here and there
+    // (chapter-16's CSG dice differ in the last bits, f32 only), and a frame must not depend on how it is sharded.
+    const long long frame_tiles = (long long)rp.tiles_x * ((c->vsize + 7) / 8);
+    const bool spread = first_samples > 1 && first_samples <= 64 && frame_tiles < (long long)s->num_cu * 12 * spread_below();
+    rp.first = (uint32_t)first_samples;
+    rp.group = spread ? (uint32_t)first_samples : 1u;
+    rp.ppw = 64u / rp.group;
+    const unsigned long long visits = ((unsigned long long)rp.n_tiles * 64u + rp.ppw - 1) / rp.ppw;
+    if (visits > 0x7FFFFFFFull) return fail(RTMI_ERR_UNSUPPORTED, "frame too large for one call");
+    rp.n_visits = (uint32_t)visits;
+    const int per_cu = (!spread && first_samples >= 4) ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU;
+    int grid = (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * per_cu);
+    grid = std::max(std::min(grid, (int)((visits + 2) / 3)), (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * 12));
     bool f64 = o && o->precision == RTMI_PRECISION_F64;
     if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
     const bool tree = s->h32.root_child_count != 0;
@@ -637,8 +661,6 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
         HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st));
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
-    // (adaptive renders pop their tiles - render_kernel - so the first pass too is one resident set of persistent waves)
-    if (open_ended && RTMI_DYNAMIC_TILES) grid = std::min(rp.n_tiles, s->num_cu * 4 * RTMI_RESAMPLE_WAVES);
     if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, work_bytes());
     else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, work_bytes());
     HIP_TRY(hipGetLastError());

@@ -148,7 +148,7 @@ struct DRender {
     int32_t rank, nranks, tile_rows;
     int32_t tiles_x, local_tile_rows8; // 8-row tile rows owned by this rank
     int32_t n_tiles;
-    uint32_t tile_step; // coprime to n_tiles: the k-th tile popped is k * tile_step mod n_tiles (neighbours cost alike: scatter them)
+    uint32_t first, group, ppw, n_visits; // first pass (render_kernel): samples before a pixel's fate is decided, lanes per pixel, pixels per wave visit = 64 / group, visits
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -129,7 +129,7 @@ __device__ __forceinline__ void push_heavy(uint32_t *__restrict__ hdr, DWorkItem
 // on when one is empty; and a pop takes several items while the sublist is long and single ones near its end, so that
 // the launch ends evenly.  Counters only grow and a wave leaves a sublist for good: every wave runs out of lists.
 constexpr uint32_t POP_LISTS = 16;
-enum { POP_LIGHT = 0, POP_HEAVY = 1, POP_FINAL = 2, POP_TILES = 3, POP_UNITS = 4 /* + pass */, POP_QUEUES = 4 + 8 };
+enum { POP_LIGHT = 0, POP_HEAVY = 1, POP_FINAL = 2, POP_UNITS = 3 /* + pass */, POP_QUEUES = 3 + 8 };
 static_assert((64 + POP_QUEUES * POP_LISTS * 32) * 4 <= WORK_HEADER_BYTES, "pop counters fit the header");
 struct Popper {
     uint32_t list, done, seen; // the sublist this wave is at, how many it has left behind, the last head it saw there
@@ -163,7 +163,7 @@ __device__ __forceinline__ bool pop(uint32_t *__restrict__ hdr, int queue, uint3
 // out.  The others - a few per cent of the frame, needing anything from one to thousands of further samples - are
 // appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
-template <typename R, bool TREE>
+template <typename R, bool TREE, bool SPREAD>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
@@ -177,34 +177,50 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int sub = rp.tile_rows >> 3; // 8-row rows per ownership tile
-    // With work memory at hand (an adaptive render) the waves pop their tiles instead of striding over them: tiles
-    // differ by an order of magnitude, and on a small shard (an 8-GPU run) a wave's handful of tiles does not average out.
-    const bool dynamic = RTMI_DYNAMIC_TILES && wk_hdr != nullptr;
-    __shared__ Popper tile_pop;
-    if (dynamic) { pop_begin(tile_pop); __syncthreads(); }
-    for (int tile = blockIdx.x;; tile += gridDim.x) {
-        if (dynamic) {
-            uint32_t t0 = 0, t1 = 0;
-            if (!pop(wk_hdr, POP_TILES, (uint32_t)rp.n_tiles, 1u, 1u, tile_pop, t0, t1, lane)) break;
-            tile = (int)(((unsigned long long)t0 * rp.tile_step) % (uint32_t)rp.n_tiles);
-        } else if (tile >= rp.n_tiles) break;
+    // A wave visit takes the first rp.first samples of rp.ppw pixels, in one of two ways that add the samples up in the
+    // same order (the host chooses by the size of the whole frame, rtmi.hip launch_render):
+    //   group == 1: one pixel per lane, its samples one after the other.  All 64 lanes busy; but a visit of an 8x8 tile
+    //               on the glass spheres is five deep samples in a row - 1 ms - and that is the end of the launch.
+    //   group == first (<= 64): lane = pixel slot * group + sample, one sample per lane, added up in sample order by
+    //               the pixel's first lane.  64 / group * group lanes busy (60 of 64 at 5 samples), a visit is one sample
+    //               long: small frames finish in half the time (teapot at 960x540: 11.2 -> 5.7 ms, chapter-11a at
+    //               640x360: 3.5 -> 2.7 ms), large ones lose 15 %.
+    // Pixels are numbered tile by tile, row-major inside the 8x8 tile.
+    // (SPREAD = the second way; a template parameter because one kernel for both ways spilled 10 more registers in the first)
+    const uint32_t g = SPREAD ? rp.group : 1u, slot_k = (uint32_t)lane / g, sidx = (uint32_t)lane - slot_k * g;
+    const uint32_t first = SPREAD ? g : rp.first; // samples in a pixel's sums when its fate is first decided
+    for (uint32_t visit = blockIdx.x; visit < rp.n_visits; visit += gridDim.x) {
+        const unsigned long long q = (unsigned long long)visit * rp.ppw + slot_k;
+        const int tile = (int)(q >> 6), in_tile = (int)(q & 63u);
         int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
         int lt = ltr / sub, within = ltr - lt * sub;
         int gt = lt * rp.nranks + rp.rank;
-        const int x = tx * 8 + (lane & 7), y = (gt * sub + within) * 8 + (lane >> 3);
-        const int ly = ltr * 8 + (lane >> 3);
-        const bool valid = x < cam.hsize && y < cam.vsize;
+        const int x = tx * 8 + (in_tile & 7), y = (gt * sub + within) * 8 + (in_tile >> 3);
+        const int ly = ltr * 8 + (in_tile >> 3);
+        const bool valid = slot_k < rp.ppw && tile < rp.n_tiles && x < cam.hsize && y < cam.vsize;
+        const bool owner = valid && sidx == 0; // the lane that keeps the pixel's sums
         V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
         uint32_t cnt = 0;
-        const uint32_t first = cam.max_samples > 0 && cam.max_samples < cam.min_samples ? (uint32_t)cam.max_samples : (uint32_t)cam.min_samples;
-        bool go = valid, queued = false;
-        while (go) { // wave-uniform for the first `first` iterations; afterwards only lanes without a queue slot stay
-            V3<R> c = take_sample<R, TREE>(sc, cam, rng, st, x, y, cnt);
-            sum = sum + c; sos = sos + squares(c);
-            ++cnt;
-            if (cnt < first) continue;
+        bool go = SPREAD ? true : valid, queued = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
+        while (go) { // wave-uniform until the pixels' sums hold `first` samples; afterwards only owners without a queue slot stay
+            V3<R> c = mk<R>(0, 0, 0);
+            if (!SPREAD || valid) c = take_sample<R, TREE>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
+            if (grouped) { // the owner adds its group's samples up in sample order, like the reference's loop (camera.rs:277-285)
+                grouped = false;
+                sum = c; sos = squares(c);
+                for (uint32_t k = 1; k < g; ++k) {
+                    const V3<R> ck = {__shfl_down(c.x, k, 64), __shfl_down(c.y, k, 64), __shfl_down(c.z, k, 64)};
+                    sum = sum + ck; sos = sos + squares(ck);
+                }
+                cnt = g;
+                if (!owner) break;
+            } else {
+                sum = sum + c; sos = sos + squares(c);
+                ++cnt;
+                if (cnt < first) continue;
+            }
             bool more = need_more(cam, sum, sos, (R)cnt, cnt);
-            if (more && cnt == first && wk_hdr) { // decided once per pixel, by all such lanes of the tile together
+            if (more && cnt == first && wk_hdr) { // decided once per pixel, by all such lanes of the visit together
                 // predicted samples still to take: the loop stops when variance / n <= SE^2
                 const R inv_n = rcp_((R)cnt);
                 const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean);
@@ -228,7 +244,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
             }
             go = more;
         }
-        if (valid && !queued) {
+        if (owner && !queued) {
             R inv = (R)1 / (R)cnt;
             size_t o = ((size_t)ly * cam.hsize + x) * 3;
             out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
@@ -616,8 +632,11 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
                                      const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
                                      size_t work_bytes) {
     DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
-    if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
-    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    const bool spread = rp.group > 1;
+    if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    else if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    else if (spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     if (!wk.hdr || grid_resample <= 0) return;
     for (int l = 0; l <= RTMI_SPEC_PASSES + 1; ++l) {
         const int pass = l <= RTMI_SPEC_PASSES ? l : -1;

@@ -33,13 +33,6 @@ enum {
     WK_UNIT_COUNT = 8   // + pass (1 .. RTMI_SPEC_PASSES)
 };
 static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
-#ifndef RTMI_DYNAMIC_TILES
-#define RTMI_DYNAMIC_TILES 0 // 1: in adaptive renders the first pass is one resident set of waves that pop tiles (scattered by a
-// coprime stride) instead of many waves striding over them.  Measured on chapter-11a at 3840x2160: one call alone 10.4 -> 10.1 ms
-// on the whole frame, 1.42 -> 1.19 ms first pass on a 1/8 shard (a tile on the glass spheres is 1 ms by itself: five deep samples
-// per lane), but with 3 frames in flight - what bench.py runs - 8.40 -> 8.35 ms and 1.38 -> 1.48 ms: resident waves of one frame
-// keep the next frame's kernels out longer than short-lived waves do.  Off.
-#endif
 #ifndef RTMI_LIGHT_NEED
 #define RTMI_LIGHT_NEED 192 // predicted further samples up to which a pixel goes to the light queue
 #endif
