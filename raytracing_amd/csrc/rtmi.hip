@@ -630,11 +630,9 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     // 32 by 11 % with 5 samples per visit, 32 beats 96 by 50 % with one; a wave with a single visit is mostly launch
     // cost: at least 3 visits per wave while that still fills the GPU).
     const int first_samples = std::max(1, (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples);
-    // The choice looks at the WHOLE frame, never at this rank's share: the two instantiations add the same samples in
-    // the same order, but the compiler fuses multiply-adds inside a sample's arithmetic differently here and there
-    // (chapter-16's CSG dice differ in the last bits, f32 only), and a frame must not depend on how it is sharded.
-    const long long frame_tiles = (long long)rp.tiles_x * ((c->vsize + 7) / 8);
-    const bool spread = first_samples > 1 && first_samples <= 64 && frame_tiles < (long long)s->num_cu * 12 * spread_below();
+    // (Both instantiations round every sample alike - Makefile, -ffp-contract=on - so the choice may look at this rank's
+    // share of the frame without the image depending on the sharding: tests/test_gpu_first_pass_modes.py.)
+    const bool spread = first_samples > 1 && first_samples <= 64 && (long long)rp.n_tiles < (long long)s->num_cu * 12 * spread_below();
     rp.first = (uint32_t)first_samples;
     rp.group = spread ? (uint32_t)first_samples : 1u;
     rp.ppw = 64u / rp.group;
