@@ -243,6 +243,23 @@ struct Layout {
             }
         }
         o.leaf_count = (uint32_t)leaf_orig.size() - o.leaf_first;
+        // Two boxed inner children (every split of a BoundingGroup, aabb.rs:45-70): put the one with the smaller centre
+        // along the axis that separates them most first and note the axis, so that the traversal can visit the child
+        // nearer to the ray's origin first and the running closest hit prunes the other more often.
+        if (sub.size() == 2) {
+            const rtmi_node &a = d->nodes[sub[0].first], &b = d->nodes[sub[1].first];
+            DNode ta, tb;
+            if (make_box(a, ta) && make_box(b, tb)) {
+                int axis = 0;
+                double sep = -1;
+                for (int k = 0; k < 3; ++k) {
+                    double ca = a.aabb_min[k] + a.aabb_max[k], cb = b.aabb_min[k] + b.aabb_max[k];
+                    if (std::fabs(ca - cb) > sep) { sep = std::fabs(ca - cb); axis = k; }
+                }
+                if (a.aabb_min[axis] + a.aabb_max[axis] > b.aabb_min[axis] + b.aabb_max[axis]) std::swap(sub[0], sub[1]);
+                o.flags |= (uint32_t)(axis + 1) << NODE_AXIS_SHIFT;
+            }
+        }
         o.child_first = (uint32_t)nodes.size();
         o.child_count = (uint32_t)sub.size();
         nodes.resize(nodes.size() + sub.size());

@@ -54,6 +54,7 @@ constexpr uint32_t LEAF_BOUND = 1u << 11; // f32 only: fast[] = a world-space sp
 constexpr uint32_t NODE_CSGROOT = 1u << 0;
 constexpr uint32_t NODE_GATED = 1u << 1;       // box is finite and proper: may be slab-tested
 constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
+constexpr uint32_t NODE_AXIS_SHIFT = 4;         // bits 4-5: 1 + the axis along which the node's two children are sorted by centre (0: no order)
 constexpr uint32_t NODE_ALLTRI = 1u << 3;      // not a CSG root, every direct leaf is a triangle: wtris[csg_count + i] is leaf
                                                // leaf_first + i in world space (f32 path)
 
@@ -747,8 +748,12 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
             }
             st.c[RTMI_STAT_NODE_VISITS]++;
             if (!(nd.flags & NODE_CSGROOT)) {
+                // children are popped first to last; sorted children (two, by centre along an axis) last to first when the
+                // ray runs down that axis: the nearer one first
+                const uint32_t ax = (nd.flags >> NODE_AXIS_SHIFT) & 3u;
+                const bool rev = ax != 0 && (ax == 1 ? ray.d.x : ax == 2 ? ray.d.y : ray.d.z) < (R)0;
                 for (uint32_t c = nd.child_count; c-- > 0;) {
-                    const uint32_t v = nd.child_first + c;
+                    const uint32_t v = nd.child_first + (rev ? nd.child_count - 1u - c : c);
                     if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
                     else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
                     else st.c[RTMI_STAT_OVERFLOW] = 1;
