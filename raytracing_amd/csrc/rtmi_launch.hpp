@@ -34,7 +34,7 @@ enum {
 };
 static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
 #ifndef RTMI_LIGHT_NEED
-#define RTMI_LIGHT_NEED 192 // predicted further samples up to which a pixel goes to the light queue
+#define RTMI_LIGHT_NEED 128 // predicted further samples up to which a pixel goes to the light queue
 #endif
 #ifndef RTMI_LIGHT_BATCH
 #define RTMI_LIGHT_BATCH 2  // light pixels per wave (a power of two): 32 lanes per pixel
@@ -44,9 +44,12 @@ static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
 // alike: 8 at once left the waves that met the glass spheres 0.7 ms behind the others on the headline frame)
 #endif
 #ifndef RTMI_LIGHT_ROUNDS
-#define RTMI_LIGHT_ROUNDS 6 // rounds a light batch runs 32 lanes per pixel before its leftovers get the whole wave
-// (measured on chapter-11a at 3840x2160: 2 / 192 / 6 renders the frame in 9.8 ms, 8 / 24 / 4 in 10.8 ms, everything heavy in
-// 12.3 ms: rays of one pixel are coherent, rays of eight different edge pixels are not)
+#define RTMI_LIGHT_ROUNDS 4 // rounds a light batch runs 32 lanes per pixel before its leftovers get the whole wave (or are promoted)
+// (measured on chapter-11a at 3840x2160.  Before promotion existed: 2 / 192 / 6 rendered the frame in 9.8 ms, 8 / 24 / 4 in
+// 10.8 ms, everything heavy in 12.3 ms: rays of one pixel are coherent, rays of eight different edge pixels are not.  With it,
+// one call alone / 3 frames in flight, whole frame and 1/8 shard: 2 / 192 / 6 10.17 / 8.19 and 2.94 / 1.37 ms, 2 / 128 / 4 10.04 /
+// 8.16 and 2.43 / 1.28 ms, 2 / 256 / 8 10.2 / 8.19 and 3.04 / 1.40 ms; 96 / 3, 192 / 3, 128 / 2, 64 / 2, 64 / 4 like 128 / 4: a light
+// batch is the longest job of its launch, and long jobs are what a small frame cannot afford)
 #endif
 template <typename R> struct DWorkItem {
     uint32_t px, py, out_row, cnt; // global pixel, row in this rank's compact buffer, samples taken so far
