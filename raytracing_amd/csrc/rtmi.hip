@@ -604,7 +604,7 @@ static int check_camera(const rtmi_camera *c) {
 #define RTMI_GRID_PER_CU 32 // waves of the first pass per CU (they stride over the visits) when a visit is one sample
 #endif
 #ifndef RTMI_GRID_PER_CU_MANY
-#define RTMI_GRID_PER_CU_MANY 96 // ... and when every pixel takes several samples per visit
+#define RTMI_GRID_PER_CU_MANY 192 // ... and when every pixel takes several samples per visit
 #endif
 #ifndef RTMI_SPREAD_BELOW
 #define RTMI_SPREAD_BELOW 8 // a pixel's first samples go on lanes of their own when the frame has fewer 8x8 tiles than this per resident wave
@@ -644,7 +644,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     // large one pays 15 % for (idle lanes when 64 is not a multiple, no gain at the end that 40 visits per wave do not
     // give anyway).  Waves stride over the visits; more waves than the 12 resident per CU lets the hardware dispatcher
     // balance uneven visits, but each extra wave costs its launch (measured on chapter-11a at 3840x2160: 96 per CU beats
-    // 32 by 11 % with 5 samples per visit, 32 beats 96 by 50 % with one; a wave with a single visit is mostly launch
+    // 32 by 11 % with 5 samples per visit and 192 beats 96 by 3 % (one call alone; nothing with 3 frames in flight), 32 beats 96 by 50 % with one; a wave with a single visit is mostly launch
     // cost: at least 3 visits per wave while that still fills the GPU).
     const int first_samples = std::max(1, (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples);
     // (Both instantiations round every sample alike - Makefile, -ffp-contract=on - so the choice may look at this rank's
