@@ -930,6 +930,34 @@ struct Camera {
         DeviceScene scene(world);
         return render(scene, opts, stats);
     }
+
+    // The preview of render_live / render_interactive (camera.rs:162-248: pixels reach the window while the frame is
+    // traced, through trace_pixels' pixel_callback, camera.rs:250-265) - pass by pass instead of pixel by pixel,
+    // which is how a GPU delivers a frame.  Pass k renders the whole frame with at most caps[k] samples per pixel and
+    // hands it to pass_callback(k, n_passes, canvas); after the capped passes comes the frame as render() gives it
+    // (opts->max_samples, 0 = the open-ended loop), which is also what is returned.  Sample s of a pixel does not depend
+    // on the pass (counter RNG), so every pass refines the picture before it.  A callback that returns false ends the
+    // preview there, as a key event does in render_interactive (camera.rs:220-226); the canvas of that pass is returned.
+    template <class PassCallback>
+    Canvas render_progressive(const DeviceScene &scene, PassCallback &&pass_callback, const std::vector<int> &caps = {1, 4, 16, 64},
+                              const rtmi_render_opts *opts = nullptr, rtmi_stats *stats = nullptr) const {
+        rtmi_render_opts o;
+        std::memset(&o, 0, sizeof o);
+        if (opts) o = *opts;
+        const int final_cap = o.max_samples;
+        std::vector<int> passes;
+        for (int c : caps)
+            if (c > 0 && (final_cap <= 0 || c < final_cap) && (passes.empty() || c > passes.back())) passes.push_back(c);
+        passes.push_back(final_cap);
+        Canvas canvas(hsize_, vsize_);
+        for (size_t k = 0; k < passes.size(); ++k) {
+            o.max_samples = passes[k];
+            const bool last = k + 1 == passes.size();
+            canvas = render(scene, &o, last ? stats : nullptr);
+            if (!pass_callback((int)k, (int)passes.size(), static_cast<const Canvas &>(canvas))) break;
+        }
+        return canvas;
+    }
 };
 
 } // namespace rtmi

@@ -288,5 +288,12 @@ PYBIND11_MODULE(_front, m) {
                  { py::gil_scoped_release rel; cv = c.render(w, &o, nullptr); }
                  return cv;
              },
-             py::arg("world"), py::arg("seed") = 0x5EED, py::arg("max_samples") = 0, py::arg("precision") = 0);
+             py::arg("world"), py::arg("seed") = 0x5EED, py::arg("max_samples") = 0, py::arg("precision") = 0)
+        .def("render_progressive",
+             [](const Camera &c, const DeviceScene &s, py::function callback, std::vector<int> caps, uint64_t seed, int max_samples, int precision) {
+                 rtmi_render_opts o = make_opts(seed, max_samples, precision);
+                 return c.render_progressive(s, [&](int k, int n, const Canvas &cv) { return py::cast<bool>(callback(k, n, cv)); }, caps, &o, nullptr);
+             },
+             py::arg("scene"), py::arg("callback"), py::arg("caps") = std::vector<int>{1, 4, 16, 64}, py::arg("seed") = 0x5EED,
+             py::arg("max_samples") = 0, py::arg("precision") = 0);
 }
