@@ -25,13 +25,13 @@ sys.path.insert(0, %r)
 import torch
 from raytracing_amd import abi, scenes
 out = {}
-for name, build, h, v in (("ch11a", scenes.chapter11a, 320, 180), ("soft", scenes.soft_shadow, 160, 90), ("dice", scenes.chapter16, 240, 140),
+for name, build, h, v in (("ch11a", scenes.chapter11a, 320, 180), ("ch11a_f64", scenes.chapter11a, 320, 180), ("soft", scenes.soft_shadow, 160, 90), ("dice", scenes.chapter16, 240, 140),
                           ("teapot", scenes.chapter15, 240, 140), ("ch11a_big", scenes.chapter11a, 1280, 720)):
     world, cam = build(h, v)
     sc = abi.Scene(world)
     buf = torch.zeros((v, h, 3), dtype=torch.float32, device="cuda")
     st = torch.zeros(abi.N_STATS, dtype=torch.int64, device="cuda")
-    abi.render_device(sc, cam, abi.make_opts(seed=7), buf, st, torch.cuda.current_stream().cuda_stream)
+    abi.render_device(sc, cam, abi.make_opts(seed=7, precision=1 if name.endswith("_f64") else 0), buf, st, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     s = st.cpu().tolist()
     img = buf.cpu().numpy()
@@ -56,7 +56,7 @@ def test_small_work_slots_change_nothing():
     full = _render(0)
     # 2 MiB: 10922 pixels per queue, 360 units per pass.  The small frames' queues fit; their unit lists do not.
     small = _render(2)
-    for scene in ("ch11a", "soft", "dice", "teapot"):
+    for scene in ("ch11a", "ch11a_f64", "soft", "dice", "teapot"):
         assert small[scene]["sha"] == full[scene]["sha"], scene
         assert small[scene]["stats"] == full[scene]["stats"], scene
     # ... the 1280x720 frame queues three times that many pixels: the rest are finished by their first-pass lanes
