@@ -60,7 +60,10 @@ template <typename R> struct DeviceArrays {
 // created with the first scene on the device and freed with the last, so that rendering itself allocates nothing.
 // A stream is bound to a slot the first time it renders; work on one stream is ordered, so one slot per stream is
 // race-free, and renders on different streams use different slots.
-constexpr int WORK_SLOTS = 4;
+#ifndef RTMI_WORK_SLOTS
+#define RTMI_WORK_SLOTS 4
+#endif
+constexpr int WORK_SLOTS = RTMI_WORK_SLOTS;
 constexpr size_t WORK_BYTES = (size_t)2 << 30; // 2 x 11 M queued pixels (f32: a whole 3840x2160 frame per queue) + 370 k units of 64 samples; 8 GB of 288 GB per device
 // RTMI_WORK_MB (read once per process): the slot size in MiB instead, for tests that want queues, unit lists and the
 // heavy table to overflow (every overflow path is exact, only slower)

@@ -10,7 +10,7 @@ world, cam = scenes.chapter11a(H, V)
 sc = abi.Scene(world)
 rows = abi.rank_rows(V, 0, nr, 8)
 opts = abi.make_opts(rank=0, nranks=nr, tile_rows=8)
-all_streams = [torch.cuda.Stream() for _ in range(4)]
+all_streams = [torch.cuda.Stream() for _ in range(3)]
 for k in (1, 3, 1, 3):
     streams = all_streams[:k]
     bufs = [torch.zeros((rows, H, 3), dtype=torch.float32, device="cuda") for _ in range(k)]
