@@ -34,29 +34,25 @@ enum {
 };
 static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
 #ifndef RTMI_LIGHT_NEED
-#define RTMI_LIGHT_NEED 48 // predicted further samples up to which a pixel goes to the light queue
+#define RTMI_LIGHT_NEED 128 // predicted further samples up to which a pixel goes to the light queue
 #endif
 #ifndef RTMI_LIGHT_BATCH
-#define RTMI_LIGHT_BATCH 4  // light pixels per wave (a power of two): 16 lanes per pixel
+#define RTMI_LIGHT_BATCH 2  // light pixels per wave (a power of two): 32 lanes per pixel
 #endif
 #ifndef RTMI_LIGHT_POP
 #define RTMI_LIGHT_POP 1 // most light batches a wave pops at once (neighbours in the queue are neighbours in the image and cost
 // alike: 8 at once left the waves that met the glass spheres 0.7 ms behind the others on the headline frame)
 #endif
 #ifndef RTMI_LIGHT_ROUNDS
-#define RTMI_LIGHT_ROUNDS 3 // rounds a light batch runs 16 lanes per pixel before its leftovers get the whole wave (or are promoted)
-// Measured on chapter-11a at 3840x2160 as pixels per wave / need / narrow rounds.  Before promotion existed: 2 / 192 / 6 rendered the
-// frame in 9.8 ms, 8 / 24 / 4 in 10.8 ms, everything heavy in 12.3 ms: rays of one pixel are coherent, rays of eight different edge
-// pixels are not.  With it, as "one call alone / 3 frames in flight" for the whole frame and for a 1/8 shard:
-//   2 / 192 / 6   10.17 / 8.19 ms   2.94 / 1.37 ms          2 / 256 / 8   10.2 / 8.19   3.04 / 1.40
-//   2 / 128 / 4    9.72 / 8.19      2.43 / 1.28              4 / 96 / 6    10.65 / 8.11  2.77 / 1.32
-//   4 / 48 / 3    10.2 / 7.99       2.48 / 1.25  <- this     8 / 24 / 3    10.6 / 8.11   2.76 / 1.30
-//   4 / 32 / 2    10.1 / 8.00       2.46 / 1.25              4 / 48 / 2    10.2 / 8.10   2.49 / 1.27
-// A light batch is the longest job of its launch, and long jobs are what a small frame cannot afford; 4 / 48 / 3 does the least work
-// in all (fewest discarded samples) and so wins with frames in flight - what a renderer that streams frames sees, and bench.py -
-// at the price of a longer end of the launch when one call runs alone (2 / 128 / 4 is 5 % faster there).  A third queue (tiny: 4 per
-// wave, need <= 48, 3 narrow rounds, beside 2 / 128 / 4 and heavy) was built and measured too: 10.4 - 10.6 / 8.00 - 8.03 and 2.48 / 1.27
-// ms in either pop order - the same trade, not both gains.
+#define RTMI_LIGHT_ROUNDS 4 // rounds a light batch runs 32 lanes per pixel before its leftovers get the whole wave (or are promoted)
+// (measured on chapter-11a at 3840x2160.  Before promotion existed: 2 / 192 / 6 rendered the frame in 9.8 ms, 8 / 24 / 4 in
+// 10.8 ms, everything heavy in 12.3 ms: rays of one pixel are coherent, rays of eight different edge pixels are not.  With it,
+// one call alone / 3 frames in flight, whole frame and 1/8 shard: 2 / 192 / 6 10.17 / 8.19 and 2.94 / 1.37 ms, 2 / 128 / 4 10.04 /
+// 8.16 and 2.43 / 1.28 ms, 2 / 256 / 8 10.2 / 8.19 and 3.04 / 1.40 ms; 96 / 3, 192 / 3, 128 / 2, 64 / 2, 64 / 4 like 128 / 4: a light
+// batch is the longest job of its launch, and long jobs are what a small frame cannot afford.  4 pixels per wave with
+// need <= 48 and 3 narrow rounds: 10.2 / 7.99 and 2.48 / 1.26 ms - less work in all (fewer discarded samples), a longer end of the
+// launch when a call runs alone.  A third queue (tiny: 4 per wave, need <= 48, 3 narrow rounds, beside light and heavy as they
+// are) was built and measured too: 10.4 - 10.6 / 8.00 - 8.03 and 2.48 / 1.27 ms in either pop order - the same trade, not both gains)
 #endif
 template <typename R> struct DWorkItem {
     uint32_t px, py, out_row, cnt; // global pixel, row in this rank's compact buffer, samples taken so far
