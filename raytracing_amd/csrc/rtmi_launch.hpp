@@ -51,7 +51,8 @@ static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
 // 8.16 and 2.43 / 1.28 ms, 2 / 256 / 8 10.2 / 8.19 and 3.04 / 1.40 ms; 96 / 3, 192 / 3, 128 / 2, 64 / 2, 64 / 4 like 128 / 4: a light
 // batch is the longest job of its launch, and long jobs are what a small frame cannot afford.  4 pixels per wave with
 // need <= 48 and 3 narrow rounds: 10.2 / 7.99 and 2.48 / 1.26 ms - less work in all (fewer discarded samples), a longer end of the
-// launch when a call runs alone.  A third queue (tiny: 4 per wave, need <= 48, 3 narrow rounds, beside light and heavy as they
+// launch when a call runs alone - and a loss on the other scenes (as shipped, 3 frames in flight, 2 / 128 / 4 -> 4 / 48 / 3:
+// chapter-07 2.29 -> 2.61 ms, chapter-11b 3.63 -> 3.93 ms, teapot 16.3 -> 16.6 ms against chapter-11a 8.33 -> 8.20 ms).  A third queue (tiny: 4 per wave, need <= 48, 3 narrow rounds, beside light and heavy as they
 // are) was built and measured too: 10.4 - 10.6 / 8.00 - 8.03 and 2.48 / 1.27 ms in either pop order - the same trade, not both gains)
 #endif
 template <typename R> struct DWorkItem {
