@@ -925,7 +925,10 @@ static v3 trace_sample(ctx_t *cx, const rtmi_camera *cam, int x, int y, uint32_t
 /* Camera::multisample (camera.rs:273-302) */
 static v3 multisample(ctx_t *cx, const rtmi_camera *cam, int max_samples, int x, int y) {
     v3 c = trace_sample(cx, cam, x, y, 0);
-    v3 sos = vhad(c, c), sum = c;
+    /* camera.rs:277-278: BOTH accumulators start from the first sample itself - the sum of squares from c, not
+     * from c * c.  The variance estimate therefore carries an extra (c0 - c0^2) / n per channel, and a flat pixel
+     * of value c takes sqrt(mean(c - c^2)) / SE samples (50 for c = 0.5 at SE = 1e-2) instead of min_samples. */
+    v3 sos = c, sum = c;
     double n = 1.0;
     uint32_t s = 1;
     while (n < (double)cam->min_samples) {

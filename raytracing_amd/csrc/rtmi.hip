@@ -612,19 +612,30 @@ static int check_camera(const rtmi_camera *c) {
 #ifndef RTMI_SPREAD_BELOW
 #define RTMI_SPREAD_BELOW 8 // a pixel's first samples go on lanes of their own when the frame has fewer 8x8 tiles than this per resident wave
 #endif
+#ifndef RTMI_KEEP_LANES
+#define RTMI_KEEP_LANES 40 // first pass: lanes of a wave that must still be sampling for them to keep their pixels (fewer: all go to the queues)
+#endif
+#ifndef RTMI_INLANE_NEED
+#define RTMI_INLANE_NEED 96 // ... a pixel predicted to need more further samples than this goes to the queues at once
+#endif
+#ifndef RTMI_INLANE_MAX
+#define RTMI_INLANE_MAX 192 // ... and so does one that has taken this many past the first samples
+#endif
+#ifndef RTMI_INLANE_MIN_VISITS
+#define RTMI_INLANE_MIN_VISITS 8 // ... all of which applies to frames with at least this many tiles per resident wave
+#endif
 #ifndef RTMI_RESAMPLE_WAVES
 #define RTMI_RESAMPLE_WAVES 3 // waves per SIMD of the second pass's persistent grid
 #endif
 
-// RTMI_SPREAD_BELOW in the environment (read once per process) replaces the constant: 0 = never spread, a large number =
-// always; for the tests that hold both ways of the first pass against each other
-static long spread_below() {
-    static const long v = [] {
-        const char *e = getenv("RTMI_SPREAD_BELOW");
-        return e ? atol(e) : (long)RTMI_SPREAD_BELOW;
-    }();
-    return v;
+static long env_long(const char *name, long fallback) {
+    const char *e = getenv(name);
+    return e && *e ? atol(e) : fallback;
 }
+
+// RTMI_SPREAD_BELOW in the environment (read at every call) replaces the constant: 0 = never spread, a large number =
+// always; for the tests that hold both ways of the first pass against each other
+static long spread_below() { return env_long("RTMI_SPREAD_BELOW", (long)RTMI_SPREAD_BELOW); }
 
 static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st) {
     int rank = 0, nranks = 1, tr = 8;
@@ -667,9 +678,26 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     const bool tree = s->h32.root_child_count != 0;
     DCamera<double> cam = make_camera<double>(c, o);
     unsigned long long *ds = (unsigned long long *)d_stats;
-    // the open-ended part of Camera::multisample runs as a second kernel over work queues (only if it can be reached)
-    // (with min_samples <= 1 every pixel stops at its first sample - the variance of one sample is zero - so there is nothing to queue)
-    const bool open_ended = std::isfinite(c->allowed_standard_error) && cam.min_samples > 1 && !(cam.max_samples > 0 && cam.max_samples <= cam.min_samples);
+    // The open-ended part of Camera::multisample (camera.rs:290-299) runs over work queues - if it can be reached at all.
+    // The reference seeds the sum of squares with the first sample un-squared (camera.rs:277), so even one sample has a
+    // "variance": mean(c - c^2) <= 1/4 for any colour.  With min_samples <= 1 nothing can follow the first sample only
+    // when SE^2 is above that bound (the deterministic set-up of camera.rs:378-389: min 1, SE 1.0); render_interactive's
+    // min 1 / SE 0.1 (camera.rs:182) does take more.
+    const bool one_sample = cam.min_samples <= 1 && cam.se2 >= 0.2501;
+    const bool open_ended = std::isfinite(c->allowed_standard_error) && !one_sample && !(cam.max_samples > 0 && cam.max_samples <= first_samples);
+    // How long a lane of the first pass keeps its pixel past the first samples (render_kernel): on a large frame most
+    // pixels need a few dozen samples (a flat mid-grey pixel takes sqrt(c - c^2) / SE of them, see above) and are cheapest
+    // where they are; on a small frame - or a small share of one - a wave has few visits and a visit of many samples
+    // in a row would be the end of the launch, so everything past the first samples goes to the queues.
+    // (the environment replaces the constants, read at every call: tuning sweeps, and the tests that hold the policies
+    // against each other bit for bit)
+    const long env_keep = env_long("RTMI_KEEP_LANES", RTMI_KEEP_LANES), env_need = env_long("RTMI_INLANE_NEED", RTMI_INLANE_NEED),
+               env_max = env_long("RTMI_INLANE_MAX", RTMI_INLANE_MAX), env_visits = env_long("RTMI_INLANE_MIN_VISITS", RTMI_INLANE_MIN_VISITS);
+    const bool inlane = open_ended && !spread && (long long)rp.n_tiles >= (long long)s->num_cu * 12 * env_visits;
+    rp.keep_lanes = inlane ? (uint32_t)std::max(1l, std::min(64l, env_keep)) : 65u;
+    rp.inlane_need = (uint32_t)std::max(0l, env_need);
+    rp.inlane_max = inlane ? (uint32_t)std::max(0l, env_max) : 0u;
+    rp.pad = 0;
     void *work = nullptr;
     std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
     if (open_ended) {

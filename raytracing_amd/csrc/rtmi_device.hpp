@@ -150,6 +150,8 @@ struct DRender {
     int32_t tiles_x, local_tile_rows8; // 8-row tile rows owned by this rank
     int32_t n_tiles;
     uint32_t first, group, ppw, n_visits; // first pass (render_kernel): samples before a pixel's fate is decided, lanes per pixel, pixels per wave visit = 64 / group, visits
+    uint32_t keep_lanes, inlane_need, inlane_max, pad; // first pass: a lane keeps its pixel past `first` samples while at least keep_lanes lanes of its wave do, the
+                                                        // pixel is predicted to need at most inlane_need more, and it has taken fewer than first + inlane_max
 };
 
 // ---------------------------------------------------------------------------------------------

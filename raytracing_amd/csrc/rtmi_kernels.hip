@@ -88,13 +88,25 @@ __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<
     return color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
 }
 
-// The 64-sample units a pixel with these running sums would be given in a pass: what the stopping rule
-// (variance / n <= SE^2) predicts it still needs, within RTMI_SPEC_MAX and the camera's sample cap.  Only the amount
-// of work done ahead depends on this; the pixel's result does not.
+// Further samples the stopping rule is expected to ask of a pixel with these running sums.  The reference's sum of squares
+// starts from the first sample un-squared (camera.rs:277), so what it compares with SE^2 is (V + A / n) / n with
+// V = the samples' variance and A = mean(c0 - c0^2) (c0 ~ the mean): the loop stops at the n that solves
+// SE^2 n^2 - V n - A = 0.  Only how work is scheduled depends on this; no pixel's result does.
+template <typename R> __device__ __forceinline__ R predict_want(const DCamera<double> &cam, V3<R> sum, V3<R> sos, uint32_t cnt) {
+    const R inv_n = rcp_((R)cnt), third = (R)(1.0 / 3.0);
+    const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean), a3 = mean - had(mean, mean);
+    const R q = (var.x + var.y + var.z) * third;
+    const R a = max_((a3.x + a3.y + a3.z) * third, (R)0);
+    const R v = max_(q - a * inv_n, (R)0);
+    const R se2 = (R)cam.se2;
+    const R n = div_(v + sqrt_(v * v + (R)4 * se2 * a), (R)2 * se2);
+    return n - (R)cnt;
+}
+
+// The 64-sample units a pixel with these running sums would be given in a pass: what predict_want says it still
+// needs, within RTMI_SPEC_MAX and the camera's sample cap.
 template <typename R> __device__ __forceinline__ uint32_t predict_units(const DCamera<double> &cam, V3<R> sum, V3<R> sos, uint32_t cnt) {
-    const R inv_n = rcp_((R)cnt);
-    const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean);
-    const R want = div_(var.x + var.y + var.z, (R)3 * (R)cam.se2) - (R)cnt;
+    const R want = predict_want(cam, sum, sos, cnt);
     uint32_t lim = (uint32_t)RTMI_SPEC_MAX;
     if (cam.max_samples > 0) lim = min(lim, ((uint32_t)cam.max_samples - cnt + 63u) >> 6);
     lim = max(lim, 1u);
@@ -201,13 +213,15 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
         const bool owner = valid && sidx == 0; // the lane that keeps the pixel's sums
         V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
         uint32_t cnt = 0;
-        bool go = SPREAD ? true : valid, queued = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
-        while (go) { // wave-uniform until the pixels' sums hold `first` samples; afterwards only owners without a queue slot stay
+        bool go = SPREAD ? true : valid, queued = false, full = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
+        while (go) { // wave-uniform until the pixels' sums hold `first` samples
             V3<R> c = mk<R>(0, 0, 0);
             if (!SPREAD || valid) c = take_sample<R, TREE>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
-            if (grouped) { // the owner adds its group's samples up in sample order, like the reference's loop (camera.rs:277-285)
+            // camera.rs:277-278: BOTH sums start from the first sample itself - the sum of squares from c, not from c * c -
+            // and only the later samples enter it squared (camera.rs:286,297)
+            if (grouped) { // the owner adds its group's samples up in sample order, like the reference's loop
                 grouped = false;
-                sum = c; sos = squares(c);
+                sum = c; sos = c;
                 for (uint32_t k = 1; k < g; ++k) {
                     const V3<R> ck = {__shfl_down(c.x, k, 64), __shfl_down(c.y, k, 64), __shfl_down(c.z, k, 64)};
                     sum = sum + ck; sos = sos + squares(ck);
@@ -215,32 +229,41 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
                 cnt = g;
                 if (!owner) break;
             } else {
-                sum = sum + c; sos = sos + squares(c);
+                sum = sum + c; sos = sos + (cnt == 0 ? c : squares(c));
                 ++cnt;
                 if (cnt < first) continue;
             }
             bool more = need_more(cam, sum, sos, (R)cnt, cnt);
-            if (more && cnt == first && wk_hdr) { // decided once per pixel, by all such lanes of the visit together
-                // predicted samples still to take: the loop stops when variance / n <= SE^2
-                const R inv_n = rcp_((R)cnt);
-                const V3<R> mean = sum * inv_n, var = sos * inv_n - had(mean, mean);
-                const R want = div_(var.x + var.y + var.z, (R)3 * (R)cam.se2) - (R)cnt;
-                const bool heavy = want > (R)RTMI_LIGHT_NEED;
-                const unsigned long long mh = __ballot(heavy), ml = __ballot(!heavy);
-                const unsigned long long mine = heavy ? mh : ml;
-                const int leader = __ffsll((long long)mine) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&wk_hdr[heavy ? WK_HEAVY_COUNT : WK_LIGHT_COUNT], (uint32_t)__popcll(mine));
-                base = __shfl(base, leader, 64);
-                const uint32_t slot = base + (uint32_t)__popcll(mine & lt_mask);
-                if (slot < wk_cap) {
-                    DWorkItem<R> *q = (heavy ? wk_heavy : wk_light) + slot;
-                    q->px = (uint32_t)x; q->py = (uint32_t)y; q->out_row = (uint32_t)ly; q->cnt = cnt;
-                    q->sum[0] = sum.x; q->sum[1] = sum.y; q->sum[2] = sum.z;
-                    q->sos[0] = sos.x; q->sos[1] = sos.y; q->sos[2] = sos.z;
-                    queued = true;
-                    more = false;
-                } // else: the queue is full and this lane finishes its pixel alone (slow, still exact)
+            if (wk_hdr && !full) {
+                // Who goes on here, who goes to the queues.  A lane keeps its pixel while the wave stays well filled: no
+                // queue traffic, no samples taken ahead of the rule, neighbouring pixels on neighbouring lanes.  It hands
+                // the pixel over - sums and count - when the pixel is predicted to need much more (its samples are then
+                // better spread over a whole wave), when it has been here long enough, or when so few lanes of the wave
+                // are left that the others would idle.  (The sums are the reference's sequential ones on either side,
+                // so the frame does not depend on any of this.)
+                const R want = more ? predict_want(cam, sum, sos, cnt) : (R)0;
+                bool leave = more && (SPREAD || !(want <= (R)rp.inlane_need) || cnt >= first + rp.inlane_max);
+                if (!SPREAD && (uint32_t)__popcll(__ballot(more && !leave)) < rp.keep_lanes) leave = more;
+                if (leave) {
+                    const bool heavy = want > (R)RTMI_LIGHT_NEED;
+                    const unsigned long long mh = __ballot(heavy), ml = __ballot(!heavy);
+                    const unsigned long long mine = heavy ? mh : ml;
+                    const int leader = __ffsll((long long)mine) - 1;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&wk_hdr[heavy ? WK_HEAVY_COUNT : WK_LIGHT_COUNT], (uint32_t)__popcll(mine));
+                    base = __shfl(base, leader, 64);
+                    const uint32_t slot = base + (uint32_t)__popcll(mine & lt_mask);
+                    if (slot < wk_cap) {
+                        DWorkItem<R> *q = (heavy ? wk_heavy : wk_light) + slot;
+                        q->px = (uint32_t)x; q->py = (uint32_t)y; q->out_row = (uint32_t)ly; q->cnt = cnt;
+                        q->sum[0] = sum.x; q->sum[1] = sum.y; q->sum[2] = sum.z;
+                        q->sos[0] = sos.x; q->sos[1] = sos.y; q->sos[2] = sos.z;
+                        queued = true;
+                        more = false;
+                    } else { // the queue is full: this lane finishes its pixel alone (slow, still exact) and asks no more
+                        full = true;
+                    }
+                }
             }
             go = more;
         }
@@ -253,16 +276,36 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
     flush_stats(st, stats);
 }
 
-// inclusive prefix sums of a colour and its square over the G lanes of a group, in lane order (the association depends
-// on the lane's place j in its group only)
-template <typename R> __device__ __forceinline__ void group_prefix(V3<R> &ps, V3<R> &pq, int G, int j) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        if (off < G) {
-            V3<R> a = {__shfl_up(ps.x, off, 64), __shfl_up(ps.y, off, 64), __shfl_up(ps.z, off, 64)};
-            V3<R> b = {__shfl_up(pq.x, off, 64), __shfl_up(pq.y, off, 64), __shfl_up(pq.z, off, 64)};
-            if (j >= off) { ps = ps + a; pq = pq + b; }
-        }
+// lane l takes lane l - 1's value, lane 0 takes `fill` (v_mov_b32 with the wave_shr:1 DPP control: one full-rate
+// instruction per dword, no LDS).  Every lane of the wave must be active.
+__device__ __forceinline__ float wave_shr1(float fill, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_shr1(double fill, double v) {
+    const unsigned long long f = __builtin_bit_cast(unsigned long long, fill), x = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)f, (int)(uint32_t)x, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(f >> 32), (int)(uint32_t)(x >> 32), 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Camera::multisample adds a pixel's samples to its sums one after the other (camera.rs:285-286,296-297).  Here a group
+// of G lanes holds G consecutive samples of one pixel (lane j of the group: sample j) whose sums so far are sum0 / sos0:
+// sj / qj become the sums after samples 0 .. j in exactly the reference's association, ((sum0 + c_0) + c_1) + ... + c_j,
+// so that neither the image nor a stop decision depends on how many lanes, waves or launches took the samples.  A chain
+// of G dependent additions has no parallel form that rounds alike; it runs as a systolic pass instead: in every step
+// each lane adds its own sample to its left neighbour's partial sum; lane j holds its final value from step j on
+// (recomputing it from a final left neighbour gives the same bits).  G - 1 steps of 6 shifted additions.
+template <typename R>
+__device__ __forceinline__ void seq_scan(V3<R> sum0, V3<R> sos0, V3<R> c, int G, int j, V3<R> &sj, V3<R> &qj) {
+    const V3<R> q = squares(c);
+    sj = sum0 + c; qj = sos0 + q;
+    const bool head = j == 0;
+#pragma unroll 1
+    for (int step = 1; step < G; ++step) {
+        V3<R> ts = {wave_shr1(sum0.x, sj.x), wave_shr1(sum0.y, sj.y), wave_shr1(sum0.z, sj.z)};
+        V3<R> tq = {wave_shr1(sos0.x, qj.x), wave_shr1(sos0.y, qj.y), wave_shr1(sos0.z, qj.z)};
+        if (head) { ts = sum0; tq = sos0; }
+        sj = ts + c; qj = tq + q;
     }
 }
 
@@ -303,9 +346,8 @@ __device__ __forceinline__ void sum_up_units(const DCamera<double> &cam, float *
 #pragma unroll
             for (int k = 0; k < CHUNK_STAT_WORDS; ++k) nst[k] = ch->st[k][lane];
         }
-        V3<R> pq = squares(ps);
-        group_prefix(ps, pq, 64, lane);
-        const V3<R> sj = sum + ps, qj = sos + pq;
+        V3<R> sj, qj;
+        seq_scan(sum, sos, ps, 64, lane, sj, qj);
         const uint32_t cntj = cnt + (uint32_t)lane + 1u;
         const unsigned long long sb = __ballot(!need_more(cam, sj, qj, (R)cntj, cntj));
         const int k = sb ? __ffsll((long long)sb) : 64;
@@ -482,10 +524,9 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
             Stats ls;
             stats_zero(ls);
             if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE>(sc, cam, rng, ls, ox, oy, s);
-            // inclusive prefix sums over the group, in sample order
-            V3<R> ps = c, pq = squares(c);
-            group_prefix(ps, pq, G, j);
-            const V3<R> sj = sum0 + ps, qj = sos0 + pq;
+            // the pixel's sums after each of the group's samples, added up one after the other like the reference's loop
+            V3<R> sj, qj;
+            seq_scan(sum0, sos0, c, G, j, sj, qj);
             const uint32_t cntj = cnt0 + (uint32_t)j + 1u;
             const bool stop = has && !need_more(cam, sj, qj, (R)cntj, cntj);
             const unsigned long long sb = __ballot(stop);

@@ -93,14 +93,16 @@ def test_baseline_scenes_one_sample(name, kw, precision):
         assert psnr(img, ref) >= 40.0
 
 
-STO = ["ch07", "ch11a", "soft", "dof"]
+STO = [("ch07", {}, 160, 80), ("ch11a", {}, 160, 80), ("ch11b", {}, 160, 80), ("soft", {}, 160, 80), ("dof", {}, 160, 80),
+       # the tree scenes (BoundingGroup / CSG traversal in the second-pass kernels), as shipped
+       ("teapot", {"lite": True}, 160, 80), ("teapot", {}, 128, 64), ("dice", {"nx": 2, "ny": 1}, 160, 80), ("dice", {}, 128, 64)]
 
 
-@pytest.mark.parametrize("name", STO)
+@pytest.mark.parametrize("name,kw,h,v", STO, ids=[n + ("-" + "-".join("%s%s" % kv for kv in k.items()) if k else "") for n, k, _, _ in STO])
 @pytest.mark.parametrize("precision", [1, 0], ids=["f64", "f32"])
-def test_adaptive_multisampling(name, precision):
+def test_adaptive_multisampling(name, kw, h, v, precision):
     """As shipped: adaptive multisampling (camera.rs:273-302) on the shared seeded stream."""
-    world, cam = scenes.BASELINE_SCENES[name](160, 80)
+    world, cam = scenes.BASELINE_SCENES[name](h, v, **kw)
     ref, rst = orc.render(world, cam)
     img, st = gpu_render(world, cam, precision)
     p = psnr(img, ref)
