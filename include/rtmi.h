@@ -227,6 +227,21 @@ int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera,
                        const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
                        void *hip_stream);
 
+/* rtmi_render_device for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc / hipFree.  Same arguments,
+ * same kernels, same image bit for bit (a pixel's result does not depend on where its samples are taken); the
+ * work memory of the adaptive second pass is not the per-stream pool but ONE array in static device memory,
+ * 96 MiB, which every GPU the library runs on holds until the process ends (its address is looked up with
+ * hipGetSymbolAddress once per device, at rtmi_scene_create).  Calls no hipMalloc, hipFree or allocating
+ * library routine; enqueues a 32 KB hipMemsetAsync on the array's counters and the same one to nine kernels.
+ * Limit: the pixels of one call (this rank's rows x hsize) must fit one work queue, 524,288 pixels in f32 mode
+ * (e.g. 960x540) and 349,525 in f64 mode; larger calls are refused with RTMI_ERR_UNSUPPORTED and a message -
+ * render larger frames in row-tile shares (opts->rank / nranks), one call after the other.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (different streams, or threads) RACE; order them.      */
+int rtmi_render_device_noalloc(const rtmi_scene *scene, const rtmi_camera *camera,
+                               const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
+                               void *hip_stream);
+
 /* Replaces `Color::to_u8` over a canvas (color.rs:53-60, canvas.rs:101-107): clip to [0,1],
  * x255, round half away from zero.  Device buffers, asynchronous.                               */
 int rtmi_tonemap_u8_device(const float *d_rgb, uint8_t *d_rgb8, int64_t n_values, void *hip_stream);

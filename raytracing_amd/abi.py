@@ -13,7 +13,7 @@ STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_
 
 # every symbol include/rtmi.h declares
 SYMBOLS = (
-    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device",
+    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc",
     "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
 )
 
@@ -55,6 +55,7 @@ def lib():
         L.rtmi_scene_destroy.restype = None
         L.rtmi_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.POINTER(Stats)]
         L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtmi_render_device_noalloc.argtypes = L.rtmi_render_device.argtypes
         L.rtmi_tonemap_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.rtmi_trace_rays.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
@@ -125,6 +126,14 @@ def render_device(scene, camera, opts, out_tensor, stats_tensor=None, stream=0):
     cam = camera.abi()
     sp = stats_tensor.data_ptr() if stats_tensor is not None else None
     check(lib().rtmi_render_device(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream), "rtmi_render_device")
+
+
+def render_device_noalloc(scene, camera, opts, out_tensor, stats_tensor=None, stream=0):
+    """rtmi_render_device_noalloc: the same call on the library's static work memory (allocates nothing; one call at a
+    time per GPU; refuses calls of more pixels than one work queue holds)."""
+    cam = camera.abi()
+    sp = stats_tensor.data_ptr() if stats_tensor is not None else None
+    check(lib().rtmi_render_device_noalloc(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream), "rtmi_render_device_noalloc")
 
 
 def tonemap_u8_device(rgb_tensor, out_tensor, stream=0):

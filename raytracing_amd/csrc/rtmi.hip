@@ -122,6 +122,35 @@ static void *pool_slot(int dev, hipStream_t st) {
     return nullptr;
 }
 
+// rtmi_render_device_noalloc: the same work memory as a file-scope array in device memory, for callers that cannot
+// allocate (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Every GPU the library runs on
+// holds its own copy of the array, at its own address, until the process ends; `scratch` itself is only the host-side
+// stand-in of the symbol, never a device address: host code uses the per-device pointer hipGetSymbolAddress gives.
+#ifndef RTMI_STATIC_SCRATCH_MB
+#define RTMI_STATIC_SCRATCH_MB 96
+#endif
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)RTMI_STATIC_SCRATCH_MB << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+static void *g_scratch_ptr[MAX_DEVICES] = {};
+
+// the address of `scratch` on device `dev`, which must be the current device (looked up once per device)
+static int static_scratch(int dev, void **out) {
+    *out = nullptr;
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(RTMI_ERR_UNSUPPORTED, "device ordinal beyond 63");
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (!g_scratch_ptr[dev]) {
+        int cur = -1;
+        HIP_TRY(hipGetDevice(&cur));
+        if (cur != dev) return fail(RTMI_ERR_DEVICE, "the scene's device is not the current HIP device");
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RTMI_ERR_DEVICE, "hipGetSymbolAddress gave no address for the static work memory");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return RTMI_OK;
+}
+
 struct rtmi_scene {
     int device = -1;
     bool pooled = false;
@@ -562,6 +591,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32);
     if (rc == RTMI_OK) rc = upload_typed<double>(desc, L, s->f64);
     if (rc == RTMI_OK && (rc = pool_acquire(dev)) == RTMI_OK) s->pooled = true;
+    void *unused_scratch = nullptr;
+    if (rc == RTMI_OK) rc = static_scratch(dev, &unused_scratch); // set-up of rtmi_render_device_noalloc, once per device
     if (rc != RTMI_OK) { rtmi_scene_destroy(s); return rc; }
     header(s, desc, L, s->f32, s->h32);
     header(s, desc, L, s->f64, s->h64);
@@ -637,7 +668,8 @@ static long env_long(const char *name, long fallback) {
 // always; for the tests that hold both ways of the first pass against each other
 static long spread_below() { return env_long("RTMI_SPREAD_BELOW", (long)RTMI_SPREAD_BELOW); }
 
-static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st) {
+static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st,
+                         void *static_work = nullptr, size_t static_bytes = 0) {
     int rank = 0, nranks = 1, tr = 8;
     if (o && o->nranks > 1) {
         nranks = o->nranks; rank = o->rank; tr = norm_tile_rows(o->tile_rows);
@@ -645,6 +677,10 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     }
     int rows = rtmi_rank_rows(c->vsize, rank, nranks, tr);
     if (rows == 0) return RTMI_OK;
+    int cur_dev = -1;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    if (cur_dev != s->device)
+        return fail(RTMI_ERR_DEVICE, "the scene lives on device " + std::to_string(s->device) + " but the current HIP device is " + std::to_string(cur_dev));
     DRender rp;
     uint64_t seed = o ? o->seed : 0;
     rp.seed_lo = (uint32_t)seed; rp.seed_hi = (uint32_t)(seed >> 32);
@@ -700,15 +736,26 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.pad = 0;
     void *work = nullptr;
     std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
+    size_t wbytes = work_bytes();
+    if (static_work) {
+        // no queue may overflow here: a frame (or rank share) is accepted only if each queue can hold every pixel of it
+        const size_t cap = f64 ? make_work<double>(static_work, static_bytes).cap : make_work<float>(static_work, static_bytes).cap;
+        const size_t pixels = (size_t)rows * (size_t)c->hsize;
+        if (pixels > cap)
+            return fail(RTMI_ERR_UNSUPPORTED, "rtmi_render_device_noalloc: " + std::to_string(pixels) + " pixels in this call, the static work memory (" +
+                                                  std::to_string(RTMI_STATIC_SCRATCH_MB) + " MiB) holds " + std::to_string(cap) + " in " + (f64 ? "f64" : "f32") +
+                                                  " mode; render in row-tile shares (opts.rank / nranks) or use rtmi_render_device");
+    }
     if (open_ended) {
         lock.lock(); // held until both kernels are enqueued: calls sharing a stream must not interleave their launches
-        work = pool_slot(s->device, st);
+        if (static_work) { work = static_work; wbytes = static_bytes; }
+        else work = pool_slot(s->device, st);
         if (!work) return fail(RTMI_ERR_UNSUPPORTED, "more than 4 streams are rendering on this device (one work-queue slot per stream)");
-        HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st));
+        HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st)); // (the array keeps the last call's contents: the counters must start at zero)
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
-    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, work_bytes());
-    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, work_bytes());
+    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, wbytes);
+    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, wbytes);
     HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }
@@ -719,6 +766,16 @@ extern "C" int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *ca
     int rc = check_camera(camera);
     if (rc != RTMI_OK) return rc;
     return launch_render(scene, camera, opts, d_rgb_out, d_stats, (hipStream_t)hip_stream);
+}
+
+extern "C" int rtmi_render_device_noalloc(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *d_rgb_out,
+                                          uint64_t *d_stats, void *hip_stream) {
+    if (!scene || !d_rgb_out) return fail(RTMI_ERR_INVALID, "null scene or output");
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    void *work = nullptr;
+    if ((rc = static_scratch(scene->device, &work)) != RTMI_OK) return rc;
+    return launch_render(scene, camera, opts, d_rgb_out, d_stats, (hipStream_t)hip_stream, work, STATIC_SCRATCH_BYTES);
 }
 
 extern "C" int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *rgb_out, rtmi_stats *stats_out) {

@@ -17,6 +17,8 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__ static
+#define __align__(n) alignas(n)
+#define HIP_SYMBOL(x) x
 
 struct dim3 {
     unsigned x, y, z;
@@ -39,6 +41,7 @@ inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+template <typename T> inline hipError_t hipGetSymbolAddress(void **p, const T &symbol) { *p = (void *)&symbol; return hipSuccess; } // a "device" array is a host array here
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
