@@ -160,6 +160,8 @@ struct rtmi_scene {
     DCsg *csgs = nullptr;
     uint32_t *leaf_orig = nullptr;
     DWTri *wtris = nullptr;
+    uint32_t *quick = nullptr; // LDS records of the first top-level leaves (rtmi_device.hpp stage_scene)
+    uint32_t n_quick = 0;
     DScene<float> h32;
     DScene<double> h64;
     int num_cu = 256;
@@ -382,7 +384,7 @@ static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout
 }
 
 template <typename R>
-static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A) {
+static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A, std::vector<uint32_t> *quick = nullptr) {
     std::vector<DLeaf<R>> leaves(L.leaf_orig.size());
     std::vector<DTri<R>> tris;
     for (size_t i = 0; i < leaves.size(); ++i) {
@@ -470,6 +472,45 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
             tris.push_back(t);
         }
     }
+    if (quick && sizeof(R) == 4) {
+        // image of the LDS block's first two tables (rtmi_device.hpp stage_scene): records of the first top-level leaves -
+        // kind | flags, material, pattern slot, -, q[4] - and the pattern slots of those of them whose material has a
+        // pattern: world point -> pattern space in one step, pattern.inv x leaf.inv (pattern.rs:52, shapes/mod.rs:268)
+        const size_t nq = std::min<size_t>(L.nodes[0].leaf_count, (size_t)LDS_QUICK);
+        quick->assign((size_t)LDS_MATS_AT, 0u);
+        uint32_t n_slots = 0;
+        for (size_t i = 0; i < nq; ++i) {
+            const DLeaf<R> &g = leaves[i];
+            const rtmi_leaf &src = d->leaves[L.leaf_orig[i]];
+            uint32_t *q = quick->data() + i * QUICK_DW;
+            uint32_t kind = g.kind;
+            float v[4] = {0, 0, 0, 0};
+            if (kind & LEAF_FAST) { kind |= LEAF_QUICK; for (int a = 0; a < 4; ++a) v[a] = (float)g.fast[a]; }
+            else if ((kind & LEAF_KIND_MASK) == RTMI_PLANE) { kind |= LEAF_QUICK; for (int a = 0; a < 4; ++a) v[a] = (float)g.inv[4 + a]; }
+            q[0] = kind; q[1] = g.material; q[2] = NONE;
+            memcpy(q + 4, v, sizeof v);
+            const int pat = d->materials[src.material].pattern;
+            const double *li = src.inv;
+            const bool affine = li[12] == 0 && li[13] == 0 && li[14] == 0 && li[15] == 1;
+            if (pat >= 0 && affine && n_slots < (uint32_t)LDS_PATS) {
+                const rtmi_pattern &ps = d->patterns[pat];
+                DPattern<float> slot;
+                memset(&slot, 0, sizeof slot);
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 4; ++c) {
+                        double acc = c == 3 ? ps.inv[4 * r + 3] : 0.0;
+                        for (int k = 0; k < 3; ++k) acc += ps.inv[4 * r + k] * li[4 * k + c];
+                        slot.inv[4 * r + c] = (float)acc;
+                    }
+                for (int a = 0; a < 3; ++a) { slot.a[a] = (float)ps.a[a]; slot.b[a] = (float)ps.b[a]; }
+                slot.kind = ps.kind;
+                static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                slot.pad = memcmp(ps.inv, ident, sizeof ident) != 0; // (as DPattern::pad: priced as a second transform)
+                memcpy(quick->data() + LDS_PATS_AT + n_slots * PAT_DW, &slot, sizeof slot);
+                q[2] = n_slots++;
+            }
+        }
+    }
     std::vector<DMaterial<R>> mats((size_t)d->n_materials);
     for (int i = 0; i < d->n_materials; ++i) {
         const rtmi_material &s = d->materials[i];
@@ -521,6 +562,12 @@ template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_d
     h.max_depth = (uint32_t)d->max_depth;
     h.root_leaf_count = L.nodes[0].leaf_count; h.root_child_first = L.nodes[0].child_first; h.root_child_count = L.nodes[0].child_count;
     h.pad = 0;
+    h.quick = nullptr; h.n_quick = 0; h.n_lds_materials = 0; h.n_lds_lights = 0; h.pad2 = 0;
+    if (sizeof(R) == 4) {
+        h.quick = s->quick; h.n_quick = s->n_quick;
+        h.n_lds_materials = d->n_materials <= LDS_MATS ? (uint32_t)d->n_materials : 0u;
+        h.n_lds_lights = d->n_lights <= LDS_LIGHTS ? (uint32_t)d->n_lights : 0u;
+    }
 }
 
 static int validate(const rtmi_scene_desc *d) {
@@ -563,7 +610,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -588,7 +635,9 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->wtris, wtris);
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
-    if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32);
+    std::vector<uint32_t> quick;
+    if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &quick);
+    if (rc == RTMI_OK) { s->n_quick = (uint32_t)std::min<size_t>(L.nodes[0].leaf_count, (size_t)LDS_QUICK); rc = upload(&s->quick, quick); }
     if (rc == RTMI_OK) rc = upload_typed<double>(desc, L, s->f64);
     if (rc == RTMI_OK && (rc = pool_acquire(dev)) == RTMI_OK) s->pooled = true;
     void *unused_scratch = nullptr;
@@ -644,13 +693,13 @@ static int check_camera(const rtmi_camera *c) {
 #define RTMI_SPREAD_BELOW 8 // a pixel's first samples go on lanes of their own when the frame has fewer 8x8 tiles than this per resident wave
 #endif
 #ifndef RTMI_KEEP_LANES
-#define RTMI_KEEP_LANES 40 // first pass: lanes of a wave that must still be sampling for them to keep their pixels (fewer: all go to the queues)
+#define RTMI_KEEP_LANES 24 // first pass: lanes of a wave that must still be sampling for them to keep their pixels (fewer: all go to the queues)
 #endif
 #ifndef RTMI_INLANE_NEED
-#define RTMI_INLANE_NEED 96 // ... a pixel predicted to need more further samples than this goes to the queues at once
+#define RTMI_INLANE_NEED 192 // ... a pixel predicted to need more further samples than this goes to the queues at once
 #endif
 #ifndef RTMI_INLANE_MAX
-#define RTMI_INLANE_MAX 192 // ... and so does one that has taken this many past the first samples
+#define RTMI_INLANE_MAX 384 // ... and so does one that has taken this many past the first samples
 #endif
 #ifndef RTMI_INLANE_MIN_VISITS
 #define RTMI_INLANE_MIN_VISITS 8 // ... all of which applies to frames with at least this many tiles per resident wave

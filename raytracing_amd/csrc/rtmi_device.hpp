@@ -47,6 +47,8 @@ constexpr uint32_t LEAF_KIND_MASK = 0xFFu;
 constexpr uint32_t LEAF_CLOSED = 1u << 8;
 constexpr uint32_t LEAF_CAST_SHADOW = 1u << 9;
 constexpr uint32_t LEAF_FAST = 1u << 10; // f32 only: sphere under a similarity transform, tested in world space (fast[])
+constexpr uint32_t LEAF_QUICK = 1u << 12; // f32 only, top-level leaves: the leaf's LDS record holds all that its intersection test and its normal need
+                                          // (a LEAF_FAST sphere: centre and squared radius; a plane: row 1 of the world->object matrix)
 constexpr uint32_t LEAF_BOUND = 1u << 11; // f32 only: fast[] = a world-space sphere (centre, radius^2, slightly inflated) that
                                           // contains the leaf; a ray whose line misses it has no roots (leaves below nodes only)
 
@@ -136,7 +138,64 @@ template <typename R> struct DScene {
     const DWTri *wtris;        // one per entry of tris (f32 scene only, else null)
     uint32_t n_leaves, n_lights, n_nodes, max_depth;
     uint32_t root_leaf_count, root_child_first, root_child_count, pad;
+    // what stage_scene copies into LDS (f32 scene only, else null / 0)
+    const uint32_t *quick;     // LDS_MATS_AT dwords: the image of the block's first two tables (quick records, pattern slots)
+    uint32_t n_quick;          // min(root_leaf_count, LDS_QUICK)
+    uint32_t n_lds_materials;  // all materials, or 0 if there are more than LDS_MATS
+    uint32_t n_lds_lights;     // all lights, or 0 if there are more than LDS_LIGHTS
+    uint32_t pad2;
 };
+
+// ---------------------------------------------------------------------------------------------
+// The scene's small tables in LDS (f32 product path; "stage small scenes' shapes and transforms in LDS").
+// Every wave (= workgroup) copies them once when its kernel starts.  A record that every lane reads at the same index
+// comes back as one broadcast LDS read, about 64 cycles after issue and with the next record's read already in flight,
+// where the scalar loads they replace cost two dependent trips to the scalar cache per leaf (kind, then the fields the
+// kind needs), a few hundred cycles each time, which three waves per SIMD cannot cover.
+//   quick records   the first LDS_QUICK top-level leaves (World::objects that are primitives), QUICK_DW dwords each:
+//                   kind | flags, material, pattern slot, -, q[4].  LEAF_QUICK: q is all the intersection test and the
+//                   normal need; other kinds go on to their full record in global memory.
+//   pattern slots   for up to LDS_PATS of those leaves whose material has a pattern: a DPattern<float> whose matrix is
+//                   pattern.inv x leaf.inv, i.e. world point -> pattern space in one step (shapes/mod.rs:268 and
+//                   pattern.rs:52 folded on the host in f64), so that a patterned hit needs nothing from global memory
+//   materials       DMaterial<float> as they are, if there are at most LDS_MATS
+//   lights          DLight<float> as they are, if there are at most LDS_LIGHTS
+// ---------------------------------------------------------------------------------------------
+// The flat-scene kernels (World::objects all primitives) use it.  The tree-scene kernels do not: their time goes into
+// node traversal, the top level is a leaf or two, and the second code path cost them registers they do not have (the
+// compiler gave resample_kernel<float, true> 248 VGPRs = 2 waves per SIMD with it).
+template <typename R, bool TREE> constexpr bool staged_v = sizeof(R) == 4 && !TREE;
+constexpr int LDS_QUICK = 16, LDS_PATS = 4, LDS_MATS = 16, LDS_LIGHTS = 4;
+constexpr int QUICK_DW = 8;
+constexpr int MAT_DW = (int)(sizeof(DMaterial<float>) / 4), LIGHT_DW = (int)(sizeof(DLight<float>) / 4), PAT_DW = (int)(sizeof(DPattern<float>) / 4);
+constexpr int LDS_PATS_AT = (LDS_QUICK + 1) * QUICK_DW; // (the leaf loop fetches one record ahead: one spare slot)
+constexpr int LDS_MATS_AT = LDS_PATS_AT + LDS_PATS * PAT_DW;
+constexpr int LDS_LIGHTS_AT = LDS_MATS_AT + LDS_MATS * MAT_DW;
+constexpr int LDS_SCENE_DW = LDS_LIGHTS_AT + LDS_LIGHTS * LIGHT_DW; // 524 dwords = 2.1 KB per wave
+static_assert(sizeof(DMaterial<float>) % 4 == 0 && sizeof(DLight<float>) % 4 == 0 && sizeof(DPattern<float>) % 4 == 0 && LDS_PATS_AT % 4 == 0 && LDS_MATS_AT % 4 == 0, "LDS scene block layout");
+__device__ __forceinline__ uint32_t *lds_scene() {
+    __shared__ __align__(16) uint32_t s_scene[LDS_SCENE_DW];
+    return s_scene;
+}
+// Called once by every kernel that traces rays, before anything else, by all lanes of the wave.
+template <typename R, bool TREE> __device__ __forceinline__ void stage_scene(const DScene<R> &sc) {
+    if constexpr (staged_v<R, TREE>) {
+        uint32_t *s = lds_scene();
+#ifdef RTMI_HOST_EMUL // (lanes run one after the other there: each fills the whole block)
+        const uint32_t first = 0, step = 1;
+#else
+        const uint32_t first = threadIdx.x & 63u, step = 64;
+#endif
+        const uint32_t nq = (uint32_t)LDS_MATS_AT, nm = sc.n_lds_materials * (uint32_t)MAT_DW, nl = sc.n_lds_lights * (uint32_t)LIGHT_DW;
+        const uint32_t *m = reinterpret_cast<const uint32_t *>(sc.materials), *l = reinterpret_cast<const uint32_t *>(sc.lights);
+        for (uint32_t i = first; i < nq; i += step) s[i] = sc.quick[i];
+        for (uint32_t i = first; i < nm; i += step) s[LDS_MATS_AT + i] = m[i];
+        for (uint32_t i = first; i < nl; i += step) s[LDS_LIGHTS_AT + i] = l[i];
+#ifndef RTMI_HOST_EMUL
+        __syncthreads(); // (one wave per workgroup: its own writes, visible to all its lanes from here on)
+#endif
+    }
+}
 
 template <typename R> struct DCamera {
     R inv[12];
@@ -203,6 +262,7 @@ template <typename R> __device__ __forceinline__ V3<R> xf_normal(const R *m, V3<
 }
 
 template <typename R> struct Ray { V3<R> o, d; };
+__device__ __forceinline__ float u2f_(uint32_t x) { return __builtin_bit_cast(float, x); }
 
 template <typename R> struct Lim;
 template <> struct Lim<float> { static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); } };
@@ -221,6 +281,7 @@ struct Rng {
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+        // (two multiplies per multiplier: a single 64-bit product, v_mad_u64_u32, measured 0.5 - 1 % slower on whole frames)
         uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -289,11 +350,11 @@ __device__ __forceinline__ void quad_roots(float a, float hb, float c, float dis
 }
 
 template <typename R>
-__device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> *tris, V3<R> o, V3<R> d, R t[4], R &u_out, R &v_out,
+__device__ __forceinline__ int local_intersect(const DLeaf<R> &g, uint32_t gkind, const DTri<R> *tris, V3<R> o, V3<R> d, R t[4], R &u_out, R &v_out,
                                                uint32_t &fl, R &det_out) {
     const R EPS = (R)RTMI_EPSILON;
     const R INF = Lim<R>::inf();
-    uint32_t kind = g.kind & LEAF_KIND_MASK;
+    uint32_t kind = gkind & LEAF_KIND_MASK;
     int n = 0;
     fl = 0;
     if (kind == RTMI_SPHERE) { // sphere.rs:47-63
@@ -332,7 +393,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
         if (ok && tmin <= tmax) { t[0] = tmin; t[1] = tmax; n = 2; }
     } else if (kind == RTMI_CYLINDER || kind == RTMI_CONE) { // cylinder.rs:36-109, cone.rs:36-120
         const bool cone = kind == RTMI_CONE;
-        fl = (g.kind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
+        fl = (gkind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
         R a = d.x * d.x + d.z * d.z, hb = o.x * d.x + o.z * d.z, c = o.x * o.x + o.z * o.z;
         if (cone) { a -= d.y * d.y; hb -= o.y * d.y; c -= o.y * o.y; } else { c -= (R)1; }
         R w0 = INF, w1 = INF, k0 = INF, k1 = INF; // wall roots, cap roots; +inf = absent
@@ -353,7 +414,7 @@ __device__ __forceinline__ int local_intersect(const DLeaf<R> &g, const DTri<R> 
                 if (y1 > g.minimum && y1 < g.maximum) { w1 = t1; ++n; }
             }
         }
-        if (caps && (g.kind & LEAF_CLOSED) && abs_(d.y) > EPS) { // intersect_caps
+        if (caps && (gkind & LEAF_CLOSED) && abs_(d.y) > EPS) { // intersect_caps
             R tc0 = div_(g.minimum - o.y, d.y), tc1 = div_(g.maximum - o.y, d.y);
             R r0 = cone ? g.minimum * g.minimum : (R)1, r1 = cone ? g.maximum * g.maximum : (R)1;
             R x0 = o.x + tc0 * d.x, z0 = o.z + tc0 * d.z;
@@ -437,13 +498,15 @@ template <typename R> __device__ __forceinline__ bool line_misses_sphere(const R
 //    triangle and head for the other (the reference's shadow-terminator artefact, which must be kept): the root is
 //    in front iff the ray travels towards the plane, i.e. sign(d . n_g) differs from the side it started on.
 template <typename R>
-__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, uint32_t origin_side,
+__device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, uint32_t gkind, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, uint32_t origin_side,
                                           R t[4], R &u, R &v, Stats &st) {
-    const uint32_t kind = g.kind & LEAF_KIND_MASK;
+    // (gkind = g.kind, handed in by callers that know it already - the top-level loop has it from the leaf's LDS record -
+    // so that the record's other fields need not wait for it)
+    const uint32_t kind = gkind & LEAF_KIND_MASK;
     uint32_t fl;
     R det = 0;
     int n = 0;
-    if (sizeof(R) == 4 && (g.kind & LEAF_FAST)) {
+    if (sizeof(R) == 4 && (gkind & LEAF_FAST)) {
         // f32 product path: a sphere whose transform is a similarity is the world-space sphere |p - c|^2 = r^2; the
         // ray parameter t is the same in both spaces (ray.rs:30-35 does not renormalise), so these are the roots of
         // sphere.rs:47-63 at a third of the arithmetic.  Roots as closest approach -+ half chord (no cancellation).
@@ -458,10 +521,10 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris
             n = 2;
             fl = F_SPHERE_HIT;
         }
-    } else if (sizeof(R) == 4 && (g.kind & LEAF_BOUND) && !is_origin && line_misses_sphere(ray, g.fast)) {
+    } else if (sizeof(R) == 4 && (gkind & LEAF_BOUND) && !is_origin && line_misses_sphere(ray, g.fast)) {
         // no roots; priced like the reference's own (missing) test of this leaf
         fl = kind == RTMI_SPHERE ? F_SPHERE_MISS : kind == RTMI_CUBE ? F_CUBE : kind >= RTMI_TRIANGLE ? F_TRI_U
-             : (g.kind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
+             : (gkind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
     } else if (kind == RTMI_PLANE) { // plane.rs:35-44 needs the y row of the object-space ray only
         const R oy = g.inv[4] * ray.o.x + g.inv[5] * ray.o.y + g.inv[6] * ray.o.z + g.inv[7];
         const R dy = g.inv[4] * ray.d.x + g.inv[5] * ray.d.y + g.inv[6] * ray.d.z;
@@ -469,7 +532,7 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris
         if (!(abs_(dy) < (R)RTMI_EPSILON)) { t[0] = div_(-oy, dy); n = 1; }
     } else {
         V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
-        n = local_intersect(g, tris, o, d, t, u, v, fl, det);
+        n = local_intersect(g, gkind, tris, o, d, t, u, v, fl, det);
     }
     st.c[RTMI_STAT_LEAF_TESTS]++;
     st.flops += F_XFORM + fl;
@@ -480,7 +543,7 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, const DTri<R> *tris
         for (int i = 1; i < 4; ++i)
             if (i < n && abs_(t[i]) < best) { best = abs_(t[i]); k = i; }
         R forced = -max_(best, (R)1e-30);
-        if ((g.kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) {
+        if (kind == RTMI_SMOOTH_TRIANGLE) {
             bool plus = (origin_side & SIDE_PLUS) != 0;
             bool towards = plus ? det < (R)0 : det > (R)0;
             if (towards) forced = -forced;
@@ -561,7 +624,7 @@ __device__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf
         const DLeaf<R> &g = sc.leaves[li];
         if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) continue;
         R t[4], u, v;
-        int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
+        int n = leaf_roots(g, g.kind, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < n) {
@@ -621,13 +684,9 @@ __device__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf
     }
 }
 
-// One leaf that is not under any CSG operator.
+// What a traversal does with the ascending roots t[0..n) of leaf li (a leaf that is not under any CSG operator).
 template <typename R, int MODE>
-__device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, const DLeaf<R> &g, const Ray<R> &ray, uint32_t origin_leaf,
-                                           uint32_t origin_side, Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
-    if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) return;
-    R t[4], u = 0, v = 0;
-    int n = leaf_roots(g, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
+__device__ __forceinline__ void apply_roots(uint32_t li, int n, const R t[4], Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open) {
     if (MODE == MODE_COLLECT) {
         int cnt = 0;
         R last_t = 0;
@@ -645,6 +704,55 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
             if (i < n && t[i] >= (R)0 && t[i] < t_limit && t[i] < best.t) { best.t = t[i]; best.leaf = li; best.ord = (uint32_t)i; }
         }
     }
+}
+
+// One leaf that is not under any CSG operator.
+template <typename R, int MODE>
+__device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, const DLeaf<R> &g, uint32_t gkind, const Ray<R> &ray, uint32_t origin_leaf,
+                                           uint32_t origin_side, Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+    if (MODE == MODE_ANY && !(gkind & LEAF_CAST_SHADOW)) return;
+    R t[4], u = 0, v = 0;
+    int n = leaf_roots(g, gkind, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
+    apply_roots<R, MODE>(li, n, t, best, t_limit, hit_leaf, hit_ord, open);
+}
+
+// A LEAF_QUICK top-level leaf from its LDS record (wave-uniform kind, q = the record's four floats): the roots leaf_roots
+// finds for the same leaf, without its record.  inv_a = 1 / (d . d) of the ray.
+template <int MODE>
+__device__ __forceinline__ void quick_leaf(uint32_t li, uint32_t kind, float q0, float q1, float q2, float q3, const Ray<float> &ray, float inv_a,
+                                           uint32_t origin_leaf, Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord,
+                                           Open<float> &open, Stats &st) {
+    float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int n = 0;
+    uint32_t fl;
+    if (kind & LEAF_FAST) { // the world-space sphere |p - c|^2 = r^2 (see leaf_roots)
+        const V3<float> oc = ray.o - mk<float>(q0, q1, q2);
+        const float a = dot(ray.d, ray.d), hb = dot(ray.d, oc);
+        const V3<float> l = oc - ray.d * (hb * inv_a);
+        const float disc4 = a * (q3 - dot(l, l));
+        fl = F_SPHERE_MISS;
+        if (!(disc4 < 0.0f)) {
+            const float tm = -hb * inv_a, hc = sqrt_(disc4) * inv_a;
+            t[0] = tm - hc; t[1] = tm + hc;
+            n = 2;
+            fl = F_SPHERE_HIT;
+        }
+    } else { // plane.rs:35-44 on the y row of the object-space ray
+        const float oy = q0 * ray.o.x + q1 * ray.o.y + q2 * ray.o.z + q3;
+        const float dy = q0 * ray.d.x + q1 * ray.d.y + q2 * ray.d.z;
+        fl = F_PLANE;
+        if (!(abs_(dy) < (float)RTMI_EPSILON)) { t[0] = div_(-oy, dy); n = 1; }
+    }
+    st.c[RTMI_STAT_LEAF_TESTS]++;
+    st.flops += F_XFORM + fl;
+    if (li == origin_leaf && n > 0) { // the spawn point itself: behind the origin (see leaf_roots)
+        const bool second = n > 1 && abs_(t[1]) < abs_(t[0]);
+        const float forced = -max_(second ? abs_(t[1]) : abs_(t[0]), 1e-30f);
+        if (second) t[1] = forced; else t[0] = forced;
+    }
+    // (measured: the general update below, which the compiler turns into two short exec-masked blocks, beats a
+    // branch-free "first root >= 0" select by 4 - 5 % on the chapter-11 frames)
+    apply_roots<float, MODE>(li, n, t, best, t_limit, hit_leaf, hit_ord, open);
 }
 
 // A triangle leaf of a NODE_ALLTRI node, tested in world space from its DWTri record alone: no leaf record, no ray
@@ -709,10 +817,37 @@ __device__ __forceinline__ uint32_t (*lds_node_stack())[64] {
 template <typename R, int MODE, bool TREE>
 __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
-    // top-level primitives: wave-uniform loop bounds -> leaf records come in through scalar loads
-    for (uint32_t li = 0; li < sc.root_leaf_count; ++li) {
-        plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
-        if (MODE == MODE_ANY && best.leaf != NONE) return;
+    // Top-level primitives: wave-uniform loop bounds.  f32: the first n_quick of them have a record in the LDS block
+    // (stage_scene), fetched one leaf ahead of its test; LEAF_QUICK ones need nothing else, the others go on to their
+    // record in global memory (scalar loads) with the kind already known.  f64, and leaves past the block: scalar loads.
+    {
+        uint32_t nq = 0, kind_next = 0;
+        float qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0, inv_a = 0;
+        if constexpr (staged_v<R, TREE>) {
+            const uint32_t *qs = lds_scene();
+            nq = sc.n_quick;
+            inv_a = rcp_(dot(ray.d, ray.d));
+            kind_next = qs[0]; qn0 = u2f_(qs[4]); qn1 = u2f_(qs[5]); qn2 = u2f_(qs[6]); qn3 = u2f_(qs[7]);
+        }
+        for (uint32_t li = 0; li < sc.root_leaf_count; ++li) {
+            bool quick = false;
+            uint32_t kind = 0;
+            if constexpr (staged_v<R, TREE>) {
+                if (li < nq) {
+                    kind = __builtin_amdgcn_readfirstlane(kind_next);
+                    const float q0 = qn0, q1 = qn1, q2 = qn2, q3 = qn3;
+                    const uint32_t *nx = lds_scene() + (li + 1u) * (uint32_t)QUICK_DW;
+                    kind_next = nx[0]; qn0 = u2f_(nx[4]); qn1 = u2f_(nx[5]); qn2 = u2f_(nx[6]); qn3 = u2f_(nx[7]);
+                    if (kind & LEAF_QUICK) {
+                        quick = true;
+                        if (!(MODE == MODE_ANY && !(kind & LEAF_CAST_SHADOW)))
+                            quick_leaf<MODE>(li, kind, q0, q1, q2, q3, ray, inv_a, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+                    }
+                } else kind = sc.leaves[li].kind;
+            } else kind = sc.leaves[li].kind;
+            if (!quick) plain_leaf<R, MODE>(sc, li, sc.leaves[li], kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            if (MODE == MODE_ANY && best.leaf != NONE) return;
+        }
     }
     if (!TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
     if (sc.root_child_count == 0) return;
@@ -780,7 +915,7 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
             }
             if (!done)
                 for (uint32_t li = w_first; li < w_first + w_count; ++li)
-                    plain_leaf<R, MODE>(sc, li, sc.leaves[li], ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+                    plain_leaf<R, MODE>(sc, li, sc.leaves[li], sc.leaves[li].kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         }
         if (MODE == MODE_ANY && best.leaf != NONE) return;
     }
@@ -914,11 +1049,29 @@ template <typename R> struct Comps {
     R n1, n2;
 };
 
-template <typename R>
-__device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, const Hit<R> &h, Comps<R> &c) {
-    const DLeaf<R> &g = sc.leaves[h.leaf];
+// (kind | flags and material of the hit leaf come back too: from the leaf's LDS record if it has one)
+template <typename R, bool TREE>
+__device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, const Hit<R> &h, Comps<R> &c, uint32_t &kind, uint32_t &material) {
     c.point = ray.o + ray.d * h.t; // Ray::position, ray.rs:26-28
     c.eyev = -ray.d;
+    c.n1 = (R)1; c.n2 = (R)1;
+    if constexpr (staged_v<R, TREE>) {
+        if (h.leaf < sc.n_quick) {
+            const uint32_t *q = lds_scene() + h.leaf * (uint32_t)QUICK_DW;
+            kind = q[0]; material = q[1];
+            if (kind & LEAF_QUICK) {
+                const V3<R> qv = mk<R>(u2f_(q[4]), u2f_(q[5]), u2f_(q[6]));
+                // sphere under a similarity: inv^T inv (p - c) is parallel to p - c; plane: inv^T (0, 1, 0) is row 1 of inv
+                const V3<R> n = normalize((kind & LEAF_FAST) ? c.point - qv : qv);
+                c.inside = dot(n, c.eyev) < (R)0;
+                c.normalv = c.inside ? -n : n;
+                c.side_plus = false;
+                return;
+            }
+        }
+    }
+    const DLeaf<R> &g = sc.leaves[h.leaf];
+    kind = g.kind; material = g.material;
     V3<R> obj_point = xf_point(g.inv, c.point);
     R u = 0, v = 0;
     V3<R> ng = mk<R>(0, 0, 0);
@@ -939,7 +1092,26 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
     c.inside = dot(n, c.eyev) < (R)0;
     c.normalv = c.inside ? -n : n;
     c.side_plus = dot(xf_vector(g.inv, c.normalv), ng) > (R)0;
-    c.n1 = (R)1; c.n2 = (R)1;
+}
+
+// a material / the refractive index of a leaf's material: from the LDS block where it holds them
+template <typename R, bool TREE> __device__ __forceinline__ DMaterial<R> load_material(const DScene<R> &sc, uint32_t id) {
+    if constexpr (staged_v<R, TREE>) {
+        if (id < sc.n_lds_materials) return *reinterpret_cast<const DMaterial<float> *>(lds_scene() + LDS_MATS_AT + id * (uint32_t)MAT_DW);
+    }
+    return sc.materials[id];
+}
+template <typename R, bool TREE> __device__ __forceinline__ R leaf_ior(const DScene<R> &sc, uint32_t leaf) {
+    uint32_t id = 0;
+    bool have = false;
+    if constexpr (staged_v<R, TREE>) {
+        if (leaf < sc.n_quick) { id = lds_scene()[leaf * (uint32_t)QUICK_DW + 1u]; have = true; }
+    }
+    if (!have) id = sc.leaves[leaf].material;
+    if constexpr (staged_v<R, TREE>) {
+        if (id < sc.n_lds_materials) return u2f_(lds_scene()[LDS_MATS_AT + id * (uint32_t)MAT_DW + 9u]); // DMaterial::ior
+    }
+    return sc.materials[id].ior;
 }
 
 // compute_refractive_indices (ray.rs:104-140) without the sorted list: a leaf is "open" in front of
@@ -952,9 +1124,9 @@ __device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &
     open.best = NONE; open.other = NONE; open.best_t = 0; open.other_t = 0; open.hit_parity = 0;
     Hit<R> dummy = {Lim<R>::inf(), NONE, 0};
     traverse<R, MODE_COLLECT, TREE>(sc, ray, origin_leaf, origin_side, dummy, h.t, h.leaf, h.ord, open, st);
-    c.n1 = open.best != NONE ? sc.materials[sc.leaves[open.best].material].ior : (R)1;
-    if (open.hit_parity & 1u) c.n2 = open.other != NONE ? sc.materials[sc.leaves[open.other].material].ior : (R)1;
-    else c.n2 = sc.materials[sc.leaves[h.leaf].material].ior;
+    c.n1 = open.best != NONE ? leaf_ior<R, TREE>(sc, open.best) : (R)1;
+    if (open.hit_parity & 1u) c.n2 = open.other != NONE ? leaf_ior<R, TREE>(sc, open.other) : (R)1;
+    else c.n2 = leaf_ior<R, TREE>(sc, h.leaf);
 }
 
 template <typename R> struct Pending { // a refraction ray waiting for its turn (materials.rs:327-331)
@@ -968,8 +1140,8 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
 // entry laid out [entry][dword][lane] (conflict-free), 12 KB per wave = 12 waves per CU, which is the occupancy the
 // register budget allows anyway; deeper entries and the f64 validation mode use a per-lane array (scratch memory).
 // Recursion depth 5/6 scenes therefore push nothing to HBM.  One wave per workgroup (blockDim.x == 64) is assumed.
-constexpr int LDS_PEND = 6;      // flat scenes
-constexpr int LDS_PEND_TREE = 4; // tree scenes share the 12 KB with the node stack (LDS_NODES)
+constexpr int LDS_PEND = 5;      // flat scenes (a ray tree of depth 5 never holds more; with the scene block: 12.3 KB per wave)
+constexpr int LDS_PEND_TREE = 4; // tree scenes share the 12 KB with the node stack (LDS_NODES); they do not stage the scene block
 constexpr uint32_t PEND_LEAF_BITS = 26, PEND_LEAF_MASK = (1u << PEND_LEAF_BITS) - 1u; // leaf | side << 26 | remaining << 27
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -1059,21 +1231,41 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
         bool spawned = false;
         if (h.leaf != NONE) {
             Comps<R> c;
-            prepare(sc, ray, h, c);
-            const DLeaf<R> &g = sc.leaves[h.leaf];
-            const DMaterial<R> m = sc.materials[g.material];
+            uint32_t kind, material;
+            prepare<R, TREE>(sc, ray, h, c, kind, material);
+            const DMaterial<R> m = load_material<R, TREE>(sc, material);
             V3<R> over_point = c.point + c.normalv * EPS;
             // Phong::color_at (materials.rs:239-244): patterns are looked up at comps.point
             V3<R> surface_color = ld3(m.color);
-            st.flops += F_PREPARE + (((g.kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) ? F_SMOOTH_NORMAL : 0u) + F_COMBINE;
+            st.flops += F_PREPARE + (((kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) ? F_SMOOTH_NORMAL : 0u) + F_COMBINE;
             if (m.pattern >= 0) {
-                const DPattern<R> &pat = sc.patterns[m.pattern];
-                surface_color = pattern_at(pat, xf_point(g.inv, c.point));
-                st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u);
+                bool done = false;
+                if constexpr (staged_v<R, TREE>) {
+                    const uint32_t slot = h.leaf < sc.n_quick ? lds_scene()[h.leaf * (uint32_t)QUICK_DW + 2u] : NONE;
+                    if (slot != NONE) { // world point -> pattern space in one step, from the LDS block
+                        const DPattern<float> &pat = *reinterpret_cast<const DPattern<float> *>(lds_scene() + LDS_PATS_AT + slot * (uint32_t)PAT_DW);
+                        surface_color = pattern_at(pat, c.point);
+                        st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u); // (priced like the reference's two steps)
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    const DPattern<R> &pat = sc.patterns[m.pattern];
+                    surface_color = pattern_at(pat, xf_point(sc.leaves[h.leaf].inv, c.point));
+                    st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u);
+                }
             }
             V3<R> surface = mk<R>(0, 0, 0);
             for (uint32_t li = 0; li < sc.n_lights; ++li) { // materials.rs:386-397
-                Incoming<R> in = incoming_at(sc.lights[li], over_point, rng);
+                Incoming<R> in;
+                bool staged = false;
+                if constexpr (staged_v<R, TREE>) {
+                    if (sc.n_lds_lights) {
+                        in = incoming_at(*reinterpret_cast<const DLight<float> *>(lds_scene() + LDS_LIGHTS_AT + li * (uint32_t)LIGHT_DW), over_point, rng);
+                        staged = true;
+                    }
+                }
+                if (!staged) in = incoming_at(sc.lights[li], over_point, rng);
                 bool in_shadow = is_shadowed<R, TREE>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
                 st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);

@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
                                                     uint32_t wk_cap) {
     // (the work pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
     // written in this kernel and fetch the wave-uniform ones with scalar loads)
+    stage_scene<R, TREE>(sc);
     Stats st;
     stats_zero(st);
     Rng rng;
@@ -446,6 +447,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
     // (what the wave knows about its pops lives in LDS: nothing of it is wanted in registers across a sample)
     __shared__ Popper seq_pop, light_pop;
     __shared__ uint32_t popped[4]; // first item and number of items popped and not begun yet, 1 if they are heavy, 1 while the heavy list lasts
+    stage_scene<R, TREE>(sc);
     pop_begin(seq_pop); pop_begin(light_pop);
     popped[0] = 0; popped[1] = 0; popped[2] = 0; popped[3] = n_seq > 0;
     __syncthreads();
@@ -558,6 +560,7 @@ template <typename R, bool TREE>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
                                                    const DWorkItem<R> *__restrict__ wk_heavy, const uint32_t *__restrict__ wk_unit_pixel,
                                                    DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass) {
+    stage_scene<R, TREE>(sc);
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
     const int lane = threadIdx.x & 63;
