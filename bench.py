@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device)")
     ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice")
     ap.add_argument("--width", type=int, default=3840)
@@ -62,13 +62,24 @@ def workload_name(a):
     return "%s, %dx%d, %s" % (names[a.scene], a.width, a.height, samp)
 
 
+def host_threads():
+    """The host cores this process may use: its CPU affinity, within the share the box gives a 1-GPU job (OMP_NUM_THREADS
+    is set to that share there - 16 - while os.cpu_count() shows the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for var in ("RTMI_CPU_THREADS", "OMP_NUM_THREADS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            return max(1, min(n, int(v)))
+    return max(1, n)
+
+
 def cpu_baseline(world, cam, a, scenes):
     """The oracle (a C/f64 port that keeps the reference's per-ray lists + recursion) timed on the host cores on a
     bounded sample of the same frame: every k-th row, k chosen so the run takes about --cpu-seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     from raytracing_amd import abi
-    threads = min(os.cpu_count() or 1, 16)
+    threads = host_threads()
     opts = abi.make_opts(seed=a.seed, max_samples=a.max_samples)
     rays = lambda st: st["primary"] + st["reflection"] + st["refraction"] + st["shadow"]
     v = cam.vsize()
@@ -86,8 +97,8 @@ def cpu_baseline(world, cam, a, scenes):
         dt = time.perf_counter() - t0
     n_rows = len(range(stride // 2, v, stride))
     return {"value": rays(st) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "every %d-th row (%d of %d rows) of the same %dx%d frame, same seed; %.1f s of CPU time on %d threads" % (
-                stride, n_rows, v, cam.hsize(), v, dt, threads)}
+            "sample": "every %d-th row (%d of %d rows) of the same %dx%d frame, same seed; %.1f s wall on %d threads = all host cores "
+                      "this job may use (the machine shows %d logical CPUs)" % (stride, n_rows, v, cam.hsize(), v, dt, threads, os.cpu_count() or 0)}
 
 
 def main():
@@ -174,16 +185,18 @@ def main():
     # per launch: the span of the timed region on the render streams / launches (with F > 1 the launches overlap, so a
     # single launch's own start-to-end time says little), and afterwards the same call alone on an idle GPU
     span_ms = max(pairs[0][0].elapsed_time(p[1]) for p in pairs)
-    serial = []
+    # ... one call alone, three times, with HIP events on its stream before, between and after the two passes
+    # (rtmi_render_device_timed) and counters of its own: the per-kernel figures of the roofline object
+    serial, first_ms, second_ms = [], [], []
+    one = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
     for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(render_streams[0]):
-            e0.record(render_streams[0])
-            abi.render_device(scene, cam, opts, bufs[0], None, render_streams[0].cuda_stream)
-            e1.record(render_streams[0])
+        one.zero_()
         torch.cuda.synchronize()
-        serial.append(e0.elapsed_time(e1))
+        with torch.cuda.stream(render_streams[0]):
+            m1, m2 = abi.render_device_timed(scene, cam, opts, bufs[0], one, render_streams[0].cuda_stream)
+        serial.append(m1 + m2); first_ms.append(m1); second_ms.append(m2)
     serial_ms = sum(serial) / len(serial)
+    one_call = {k: int(x) for k, x in zip(abi.STAT_NAMES, one.cpu().tolist())}
 
     t = torch.tensor([dt], dtype=torch.float64, device=xdev)
     tot = stats.clone().to(xdev)
@@ -222,6 +235,26 @@ def main():
                     traffic = json.load(f).get("%s_%s" % (a.scene, a.sampling))
             except Exception:
                 traffic = None
+        ms1, ms2 = sum(first_ms) / 3.0, sum(second_ms) / 3.0
+        fl2 = float(one_call["flops_second"])
+        fl1 = float(one_call["flops"]) - fl2
+        tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        tree = "tree" if a.scene in ("teapot", "dice") else "flat"
+        kernels = {
+            "render_kernel<%s, %s> (first pass)" % (a.precision, tree): {"ms": ms1, "algorithmic_flops": fl1, "achieved": tf(fl1, ms1)},
+            "resample_kernel<%s, %s> + units_kernel + sum_up_kernel (second pass)" % (a.precision, tree): {"ms": ms2, "algorithmic_flops": fl2, "achieved": tf(fl2, ms2)},
+        }
+        for kv in kernels.values():
+            kv["frac"] = kv["achieved"] / PEAK_FP32_VALU_TFLOPS
+        dominant = max(kernels, key=lambda k: kernels[k]["ms"])
+        scenes_table = None
+        tp = os.path.join(ROOT, "profiles", "r02_all_scenes.json")
+        if os.path.exists(tp):
+            try:
+                with open(tp) as f:
+                    scenes_table = json.load(f)
+            except Exception:
+                scenes_table = None
         out = {
             "metric": "Mrays/s (primary+secondary) at 3840x2160, 1/2/4/8 MI355X; % FP32 VALU peak",
             "value": rays / dt / 1e6,
@@ -241,20 +274,21 @@ def main():
                        "rays_per_step": rays // a.steps, "samples_per_step": S["samples"] // a.steps,
                        "discarded_samples_per_step": S["discarded"] // a.steps,
                        "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "render_kernel<%s> + resample_kernel<%s> + units_kernel<%s> + sum_up_kernel<%s> (the launches of one "
-                                   "rtmi_render_device call; rocprofv3 averages: profiles/)" % ((a.precision,) * 4),
-                         "kernel_ms": k_ms, "kernel_ms_alone": serial_ms,
-                         "frac_alone": flops_launch / (serial_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
-                         "algorithmic_flops_per_launch": flops_launch,
-                         "note": "FP32 vector (VALU) roofline, no MFMA on this path; algorithmic FLOPs = reference "
-                                 "arithmetic per event (DESIGN.md 'Roofline and accounting'), rank 0's launch; kernel_ms = span of "
-                                 "the timed region between HIP events on the render streams / calls (calls of frames in flight "
-                                 "overlap); kernel_ms_alone / frac_alone = one call alone on the idle GPU, HIP events around it: the "
-                                 "figure rocprofv3's per-kernel averages of a --frames-in-flight 1 run add up to; traffic = HBM "
-                                 "bytes per call from PMC passes (profiles/traffic.json)"},
+            "roofline": {"bound": "valu", "kernel": dominant, "achieved": kernels[dominant]["achieved"], "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": kernels[dominant]["frac"], "traffic": traffic,
+                         "per_kernel": kernels,
+                         "call": {"ms_alone": serial_ms, "frac_alone": flops_launch / (serial_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                  "ms_in_flight": k_ms, "frac_in_flight": achieved / PEAK_FP32_VALU_TFLOPS,
+                                  "algorithmic_flops": flops_launch},
+                         "note": "FP32 vector (VALU) roofline, no MFMA on this path.  achieved / frac = the DOMINANT kernel of one "
+                                 "rtmi_render_device call (rank 0's share): its algorithmic FLOPs (reference arithmetic per event, DESIGN.md "
+                                 "'Roofline and accounting') / its duration between HIP events recorded on the launch stream before and after "
+                                 "it (rtmi_render_device_timed, the call alone on the GPU, mean of 3, after the timed region); per_kernel has "
+                                 "both passes; call.* is the whole call: alone, and as the span of the timed region / calls with "
+                                 "frames_in_flight calls overlapping; traffic = HBM bytes per call from PMC passes (profiles/traffic.json)"},
         }
+        if scenes_table is not None:
+            out["all_configs"] = scenes_table
         if not a.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, a, scenes)
         print(json.dumps(out), flush=True)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 1
+#define RTMI_ABI_VERSION 2
 #define RTMI_EPSILON 1e-5 /* rust/src/approx_eq.rs:13 */
 
 /* ---- error codes --------------------------------------------------------------------------- */
@@ -190,7 +190,10 @@ enum {
     RTMI_STAT_AABB_TESTS = 9, /* slab tests                                                        */
     RTMI_STAT_DISCARDED = 10, /* samples computed ahead of the stopping rule and thrown away (never
                                  counted in any of the above; the oracle reports 0)                 */
-    RTMI_N_STATS = 11
+    RTMI_STAT_FLOPS_SECOND = 11, /* the part of RTMI_STAT_FLOPS that the second-pass kernels counted (samples taken from
+                                    the work queues: resample_kernel, units_kernel via sum_up_kernel); the rest is
+                                    render_kernel's.  Device path only (the oracle reports 0).                  */
+    RTMI_N_STATS = 12
 };
 
 typedef struct rtmi_stats {
@@ -226,6 +229,14 @@ int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_r
 int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera,
                        const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
                        void *hip_stream);
+
+/* Diagnostic twin of rtmi_render_device for measurement (bench.py's roofline figures): the same launches with HIP
+ * events recorded on `hip_stream` before the first pass (render_kernel), between it and the second pass
+ * (resample / units / sum_up kernels) and after it; waits for the call to finish and returns the two durations in
+ * milliseconds.  Synchronous; creates and destroys three events.  No counterpart in the reference.             */
+int rtmi_render_device_timed(const rtmi_scene *scene, const rtmi_camera *camera,
+                             const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
+                             void *hip_stream, float *ms_first_pass, float *ms_second_pass);
 
 /* rtmi_render_device for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers
  * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc / hipFree.  Same arguments,

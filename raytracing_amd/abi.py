@@ -8,12 +8,12 @@ import os
 
 from . import LIB_PATH
 
-N_STATS = 11
-STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_tests", "node_visits", "overflow", "flops", "aabb_tests", "discarded")
+N_STATS = 12
+STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_tests", "node_visits", "overflow", "flops", "aabb_tests", "discarded", "flops_second")
 
 # every symbol include/rtmi.h declares
 SYMBOLS = (
-    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc",
+    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc", "rtmi_render_device_timed",
     "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
 )
 
@@ -56,6 +56,7 @@ def lib():
         L.rtmi_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.POINTER(Stats)]
         L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtmi_render_device_noalloc.argtypes = L.rtmi_render_device.argtypes
+        L.rtmi_render_device_timed.argtypes = L.rtmi_render_device.argtypes + [C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rtmi_tonemap_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.rtmi_trace_rays.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
@@ -134,6 +135,17 @@ def render_device_noalloc(scene, camera, opts, out_tensor, stats_tensor=None, st
     cam = camera.abi()
     sp = stats_tensor.data_ptr() if stats_tensor is not None else None
     check(lib().rtmi_render_device_noalloc(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream), "rtmi_render_device_noalloc")
+
+
+def render_device_timed(scene, camera, opts, out_tensor, stats_tensor=None, stream=0):
+    """rtmi_render_device_timed: the same launches, synchronous; returns (ms of the first pass, ms of the second pass)
+    between HIP events on `stream`."""
+    cam = camera.abi()
+    sp = stats_tensor.data_ptr() if stats_tensor is not None else None
+    a, b = C.c_float(0), C.c_float(0)
+    check(lib().rtmi_render_device_timed(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream, C.byref(a), C.byref(b)),
+          "rtmi_render_device_timed")
+    return float(a.value), float(b.value)
 
 
 def tonemap_u8_device(rgb_tensor, out_tensor, stream=0):

@@ -56,15 +56,17 @@ template <typename R> struct DeviceArrays {
     DLight<R> *lights = nullptr;
 };
 
-// Work-queue memory of the adaptive second pass (rtmi_launch.hpp DWork): a per-device pool of WORK_SLOTS buffers,
-// created with the first scene on the device and freed with the last, so that rendering itself allocates nothing.
-// A stream is bound to a slot the first time it renders; work on one stream is ordered, so one slot per stream is
-// race-free, and renders on different streams use different slots.
+// Work-queue memory of the adaptive second pass (rtmi_launch.hpp DWork): a per-device pool of up to WORK_SLOTS buffers.
+// The first is created with the first scene on the device, the others the first time that many streams render at once;
+// all are freed with the device's last scene.  A slot belongs to a stream while work of that stream is in flight on it
+// (work on one stream is ordered, so one slot per stream is race-free); after every call an event is recorded on the
+// stream, and a slot whose event has completed may be given to another stream.  A process may therefore use any number
+// of streams over its life, WORK_SLOTS of them rendering at the same time.
 #ifndef RTMI_WORK_SLOTS
 #define RTMI_WORK_SLOTS 4
 #endif
 constexpr int WORK_SLOTS = RTMI_WORK_SLOTS;
-constexpr size_t WORK_BYTES = (size_t)2 << 30; // 2 x 11 M queued pixels (f32: a whole 3840x2160 frame per queue) + 370 k units of 64 samples; 8 GB of 288 GB per device
+constexpr size_t WORK_BYTES = (size_t)2 << 30; // 2 x 11 M queued pixels (f32: a whole 3840x2160 frame per queue) + 370 k units of 64 samples
 // RTMI_WORK_MB (read once per process): the slot size in MiB instead, for tests that want queues, unit lists and the
 // heavy table to overflow (every overflow path is exact, only slower)
 static size_t work_bytes() {
@@ -79,26 +81,32 @@ constexpr int MAX_DEVICES = 64;
 struct WorkPool {
     int refs = 0;
     void *buf[WORK_SLOTS] = {};
+    hipEvent_t done[WORK_SLOTS] = {}; // recorded after the last call that used the slot
     hipStream_t stream[WORK_SLOTS] = {};
-    bool used[WORK_SLOTS] = {};
+    bool bound[WORK_SLOTS] = {};      // stream[i] has (or had, until done[i] completes) work on the slot
+    unsigned long long stamp[WORK_SLOTS] = {};
+    unsigned long long clock = 0;
 };
 static std::mutex g_pool_mutex;
 static WorkPool g_pool[MAX_DEVICES];
+
+static int pool_make_slot(WorkPool &p, int i) { // (g_pool_mutex held, the pool's device current)
+    if (p.buf[i]) return RTMI_OK;
+    hipError_t e = hipMalloc(&p.buf[i], work_bytes());
+    if (e != hipSuccess) { p.buf[i] = nullptr; return fail(RTMI_ERR_NOMEM, std::string("work-queue pool: ") + hipGetErrorString(e)); }
+    e = hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipFree(p.buf[i]); p.buf[i] = nullptr; return fail(RTMI_ERR_DEVICE, std::string("work-queue pool event: ") + hipGetErrorString(e)); }
+    p.bound[i] = false;
+    return RTMI_OK;
+}
 
 static int pool_acquire(int dev) {
     if (dev < 0 || dev >= MAX_DEVICES) return fail(RTMI_ERR_UNSUPPORTED, "device ordinal beyond 63");
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     WorkPool &p = g_pool[dev];
     if (p.refs == 0) {
-        for (int i = 0; i < WORK_SLOTS; ++i) {
-            hipError_t e = hipMalloc(&p.buf[i], work_bytes());
-            if (e != hipSuccess) {
-                for (int k = 0; k < i; ++k) { (void)hipFree(p.buf[k]); p.buf[k] = nullptr; }
-                p.buf[i] = nullptr;
-                return fail(RTMI_ERR_NOMEM, std::string("work-queue pool: ") + hipGetErrorString(e));
-            }
-            p.used[i] = false;
-        }
+        int rc = pool_make_slot(p, 0);
+        if (rc != RTMI_OK) return rc;
     }
     ++p.refs;
     return RTMI_OK;
@@ -109,17 +117,39 @@ static void pool_release(int dev) {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     WorkPool &p = g_pool[dev];
     if (p.refs > 0 && --p.refs == 0)
-        for (int i = 0; i < WORK_SLOTS; ++i) { (void)hipFree(p.buf[i]); p.buf[i] = nullptr; p.used[i] = false; }
+        for (int i = 0; i < WORK_SLOTS; ++i) {
+            if (p.buf[i]) { (void)hipFree(p.buf[i]); (void)hipEventDestroy(p.done[i]); }
+            p.buf[i] = nullptr; p.done[i] = nullptr; p.bound[i] = false;
+        }
 }
 
-// the slot bound to `st` (binding it if this stream is new); nullptr when all slots belong to other streams
-static void *pool_slot(int dev, hipStream_t st) {
+// The slot for a call on stream `st` (g_pool_mutex held): the one the stream's earlier work is on, else an idle one -
+// never used, or whose last call has completed (the least recently used of those) - else a new one; -1 when WORK_SLOTS
+// streams have work in flight.
+static int pool_slot(int dev, hipStream_t st, int *slot) {
     WorkPool &p = g_pool[dev];
+    *slot = -1;
     for (int i = 0; i < WORK_SLOTS; ++i)
-        if (p.used[i] && p.stream[i] == st) return p.buf[i];
-    for (int i = 0; i < WORK_SLOTS; ++i)
-        if (!p.used[i]) { p.used[i] = true; p.stream[i] = st; return p.buf[i]; }
-    return nullptr;
+        if (p.buf[i] && p.bound[i] && p.stream[i] == st) { *slot = i; return RTMI_OK; }
+    int idle = -1;
+    for (int i = 0; i < WORK_SLOTS; ++i) {
+        if (!p.buf[i]) continue;
+        if (p.bound[i] && hipEventQuery(p.done[i]) != hipSuccess) continue; // its stream is still at work
+        p.bound[i] = false;
+        if (idle < 0 || p.stamp[i] < p.stamp[idle]) idle = i;
+    }
+    if (idle < 0)
+        for (int i = 0; i < WORK_SLOTS && idle < 0; ++i)
+            if (!p.buf[i]) {
+                int rc = pool_make_slot(p, i);
+                if (rc != RTMI_OK) return rc;
+                idle = i;
+            }
+    if (idle < 0)
+        return fail(RTMI_ERR_UNSUPPORTED, "more than " + std::to_string(WORK_SLOTS) + " streams are rendering on this device at the same time (one work-queue slot per stream with work in flight)");
+    p.bound[idle] = true; p.stream[idle] = st;
+    *slot = idle;
+    return RTMI_OK;
 }
 
 // rtmi_render_device_noalloc: the same work memory as a file-scope array in device memory, for callers that cannot
@@ -718,7 +748,7 @@ static long env_long(const char *name, long fallback) {
 static long spread_below() { return env_long("RTMI_SPREAD_BELOW", (long)RTMI_SPREAD_BELOW); }
 
 static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st,
-                         void *static_work = nullptr, size_t static_bytes = 0) {
+                         void *static_work = nullptr, size_t static_bytes = 0, hipEvent_t between = nullptr) {
     int rank = 0, nranks = 1, tr = 8;
     if (o && o->nranks > 1) {
         nranks = o->nranks; rank = o->rank; tr = norm_tile_rows(o->tile_rows);
@@ -784,6 +814,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.inlane_max = inlane ? (uint32_t)std::max(0l, env_max) : 0u;
     rp.pad = 0;
     void *work = nullptr;
+    int slot = -1;
     std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
     size_t wbytes = work_bytes();
     if (static_work) {
@@ -798,14 +829,22 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     if (open_ended) {
         lock.lock(); // held until both kernels are enqueued: calls sharing a stream must not interleave their launches
         if (static_work) { work = static_work; wbytes = static_bytes; }
-        else work = pool_slot(s->device, st);
-        if (!work) return fail(RTMI_ERR_UNSUPPORTED, "more than 4 streams are rendering on this device (one work-queue slot per stream)");
+        else {
+            int rc = pool_slot(s->device, st, &slot);
+            if (rc != RTMI_OK) return rc;
+            work = g_pool[s->device].buf[slot];
+        }
         HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st)); // (the array keeps the last call's contents: the counters must start at zero)
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
-    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, wbytes);
-    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, wbytes);
+    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, wbytes, between);
+    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, wbytes, between);
     HIP_TRY(hipGetLastError());
+    if (slot >= 0) { // the slot is this stream's until this point of the stream has been reached
+        WorkPool &p = g_pool[s->device];
+        HIP_TRY(hipEventRecord(p.done[slot], st));
+        p.stamp[slot] = ++p.clock;
+    }
     return RTMI_OK;
 }
 
@@ -815,6 +854,35 @@ extern "C" int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *ca
     int rc = check_camera(camera);
     if (rc != RTMI_OK) return rc;
     return launch_render(scene, camera, opts, d_rgb_out, d_stats, (hipStream_t)hip_stream);
+}
+
+extern "C" int rtmi_render_device_timed(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *d_rgb_out,
+                                        uint64_t *d_stats, void *hip_stream, float *ms_first_pass, float *ms_second_pass) {
+    if (!scene || !d_rgb_out || !ms_first_pass || !ms_second_pass) return fail(RTMI_ERR_INVALID, "null scene, output or duration pointer");
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+#define TRY_EV(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) { cleanup(); return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    for (hipEvent_t &e : ev) TRY_EV(hipEventCreate(&e));
+    TRY_EV(hipEventRecord(ev[0], st));
+    rc = launch_render(scene, camera, opts, d_rgb_out, d_stats, st, nullptr, 0, ev[1]);
+    if (rc != RTMI_OK) { cleanup(); return rc; }
+    TRY_EV(hipEventRecord(ev[2], st));
+    TRY_EV(hipEventSynchronize(ev[2]));
+    *ms_first_pass = 0; *ms_second_pass = 0;
+    if (hipEventQuery(ev[1]) == hipSuccess) { // (not recorded when this rank owns no rows)
+        TRY_EV(hipEventElapsedTime(ms_first_pass, ev[0], ev[1]));
+        TRY_EV(hipEventElapsedTime(ms_second_pass, ev[1], ev[2]));
+    }
+#undef TRY_EV
+    cleanup();
+    return RTMI_OK;
 }
 
 extern "C" int rtmi_render_device_noalloc(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *d_rgb_out,
@@ -882,6 +950,15 @@ extern "C" int rtmi_trace_rays(const rtmi_scene *scene, const rtmi_render_opts *
                                const int32_t *remaining, double *rgb_out, rtmi_hit_record *hits_out) {
     if (!scene || !origins || !directions || n < 0) return fail(RTMI_ERR_INVALID, "bad trace arguments");
     if (n == 0) return RTMI_OK;
+    if (n > ((int64_t)1 << 30)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^30 rays in one rtmi_trace_rays call");
+    int dev = -1, rc = ensure_device(&dev);
+    if (rc != RTMI_OK) return rc;
+    if (dev != scene->device)
+        return fail(RTMI_ERR_DEVICE, "the scene lives on device " + std::to_string(scene->device) + " but the current HIP device is " + std::to_string(dev));
+    if (remaining) // the pending-ray stack holds MAX_DEPTH entries and packs `remaining` into 5 bits
+        for (int64_t i = 0; i < n; ++i)
+            if (remaining[i] < 0 || remaining[i] > MAX_DEPTH)
+                return fail(RTMI_ERR_UNSUPPORTED, "remaining[" + std::to_string(i) + "] = " + std::to_string(remaining[i]) + " is outside [0, " + std::to_string(MAX_DEPTH) + "]");
     double *d_o = nullptr, *d_d = nullptr, *d_rgb = nullptr;
     int *d_rem = nullptr;
     rtmi_hit_record *d_rec = nullptr;

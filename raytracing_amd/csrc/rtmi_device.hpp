@@ -1303,6 +1303,7 @@ __device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &r
                 }
             }
             if (do_refl) {
+                if (do_refr && pend.full()) st.c[RTMI_STAT_OVERFLOW] = 1; // (unreachable while max_depth <= MAX_DEPTH: the ray would be lost)
                 if (do_refr && !pend.full()) {
                     Pending<R> e;
                     e.o = refr_ray.o; e.d = refr_ray.d; e.weight = w_refr;

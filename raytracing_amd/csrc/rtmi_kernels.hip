@@ -25,18 +25,22 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *__restrict__ stats) {
+// (second: the kernel belongs to the second pass, its FLOPs are reported in RTMI_STAT_FLOPS_SECOND as well)
+__device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *__restrict__ stats, bool second = false) {
     if (!stats) return;
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) {
-        if (i == RTMI_STAT_FLOPS) continue;
+        if (i == RTMI_STAT_FLOPS || i == RTMI_STAT_FLOPS_SECOND) continue;
         uint32_t s = wave_sum(st.c[i]);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
     }
     unsigned long long f = st.flops;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
-    if ((threadIdx.x & 63) == 0 && f) atomicAdd(&stats[RTMI_STAT_FLOPS], f);
+    if ((threadIdx.x & 63) == 0 && f) {
+        atomicAdd(&stats[RTMI_STAT_FLOPS], f);
+        if (second) atomicAdd(&stats[RTMI_STAT_FLOPS_SECOND], f);
+    }
 }
 
 // Camera::multisample's loop condition (camera.rs:281,290-291 with color_variance_of_mean, 305-310):
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *
             sum_up_units<R>(cam, out, wk_hdr, wk_heavy, wk_final, wk_unit_pixel, wk_chunks, wk_unit_cap, __shfl(p, i, 64), pass, st, lane);
         }
     }
-    flush_stats(st, stats);
+    flush_stats(st, stats, true);
 }
 
 // Camera::multisample's open-ended loop (camera.rs:290-299) for the pixels render_kernel queued.  Three kernels share
@@ -550,7 +554,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
             out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
         }
     }
-    flush_stats(st, stats);
+    flush_stats(st, stats, true);
 }
 
 // The units of pass `pass` (see resample_kernel): each wave pops batches of units, takes every unit's 64 samples and
@@ -674,13 +678,14 @@ namespace rtmi_dev {
 template <>
 void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hipStream_t st, const DScene<RTMI_REAL> &sc,
                                      const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
-                                     size_t work_bytes) {
+                                     size_t work_bytes, hipEvent_t between) {
     DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
     const bool spread = rp.group > 1;
     if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     else if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     else if (spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
     else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    if (between) (void)hipEventRecord(between, st); // (rtmi_render_device_timed)
     if (!wk.hdr || grid_resample <= 0) return;
     for (int l = 0; l <= RTMI_SPEC_PASSES + 1; ++l) {
         const int pass = l <= RTMI_SPEC_PASSES ? l : -1;
@@ -698,7 +703,7 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
 #else
 template <>
 void launch_render_kernel<RTMI_REAL>(bool, int, int, hipStream_t, const DScene<RTMI_REAL> &, const DCamera<double> &, const DRender &, float *,
-                                     unsigned long long *, void *, size_t) {}
+                                     unsigned long long *, void *, size_t, hipEvent_t) {}
 #endif
 template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,

@@ -52,6 +52,9 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated error"; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

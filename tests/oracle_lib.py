@@ -10,9 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 SO = os.path.join(ORACLE_DIR, "liboracle.so")
 SCHEME_N1N2 = 1
-N_STATS = 11
 
-from raytracing_amd.abi import HitRecord, RenderOpts, make_opts  # noqa: E402  (struct mirrors of include/rtmi.h)
+from raytracing_amd.abi import HitRecord, N_STATS, RenderOpts, make_opts  # noqa: E402  (struct mirrors of include/rtmi.h)
 
 _lib = None
 

@@ -235,7 +235,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = abi.lib()
     for s in declared:
         assert getattr(lib, s) is not None
-    assert abi.describe().startswith("rtmi abi=1 target=gfx950")
+    assert abi.describe().startswith("rtmi abi=2 target=gfx950")
 
 
 def test_c_abi_struct_sizes_match():

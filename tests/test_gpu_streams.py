@@ -28,12 +28,45 @@ def test_concurrent_streams_give_the_sequential_images():
         abi.render_device(sc, cam_b, abi.make_opts(seed=2), out_b, None, s2.cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(out_a.cpu().numpy(), ref_a) and np.array_equal(out_b.cpu().numpy(), ref_b)
-    # a fifth distinct stream (the null stream was used by render_host) is refused loudly, not raced
-    extra = [torch.cuda.Stream() for _ in range(3)]
-    with pytest.raises(abi.RtmiError, match="streams"):
-        for s in extra:
-            abi.render_device(sc, cam_b, abi.make_opts(seed=2), out_b, None, s.cuda_stream)
+    sc.close()
+
+
+def test_any_number_of_streams_over_time_and_four_at_once():
+    """A work-queue slot belongs to a stream only while that stream's work is in flight: a process may render on any number
+    of streams one after the other (a host that makes a stream per frame), and on up to four at the same time; a fifth
+    concurrent one is refused loudly, never raced, and is welcome again once the others have finished."""
+    import torch
+    world, cam = scenes.chapter11a(256, 128)
+    sc = abi.Scene(world)
+    ref, _ = abi.render_host(sc, cam, abi.make_opts(seed=2))
+    for _ in range(12):  # 12 short-lived streams, one after the other
+        s = torch.cuda.Stream()
+        out = torch.zeros((128, 256, 3), dtype=torch.float32, device="cuda")
+        abi.render_device(sc, cam, abi.make_opts(seed=2), out, None, s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref)
+        del s
+    # many at once: a frame that keeps the GPU busy for milliseconds, seven streams launched back to back
+    _, big = scenes.chapter11a(1280, 720)
+    streams = [torch.cuda.Stream() for _ in range(7)]
+    outs = [torch.zeros((720, 1280, 3), dtype=torch.float32, device="cuda") for _ in streams]
+    accepted = []
+    for s, o in zip(streams, outs):
+        try:
+            abi.render_device(sc, big, abi.make_opts(seed=3), o, None, s.cuda_stream)
+            accepted.append(o)
+        except abi.RtmiError as e:
+            assert "streams are rendering" in str(e)
     torch.cuda.synchronize()
+    assert 4 <= len(accepted) <= 7  # (more than four only if early ones had finished by then)
+    for o in accepted[1:]:
+        assert torch.equal(o, accepted[0])
+    # ... and afterwards every stream is welcome again
+    for s in streams:
+        out = torch.zeros((128, 256, 3), dtype=torch.float32, device="cuda")
+        abi.render_device(sc, cam, abi.make_opts(seed=2), out, None, s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref)
     sc.close()
 
 
