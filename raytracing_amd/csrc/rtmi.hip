@@ -3,10 +3,12 @@
 // RTMI_ERR_DEVICE and a message.
 #include "rtmi_launch.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -19,6 +21,15 @@ using namespace rtmi_dev;
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 extern "C" const char *rtmi_last_error(void) { return g_err.c_str(); }
+
+static long env_long(const char *name, long fallback) {
+    const char *e = getenv(name);
+    return e && *e ? atol(e) : fallback;
+}
+
+#ifndef RTMI_BVH_LEAF
+#define RTMI_BVH_LEAF 4 // most triangles in a leaf of the device's own triangle BVH (RTMI_BVH_LEAF in the environment at scene creation replaces it)
+#endif
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -190,6 +201,9 @@ struct rtmi_scene {
     DCsg *csgs = nullptr;
     uint32_t *leaf_orig = nullptr;
     DWTri *wtris = nullptr;
+    DBvh2 *bvh2 = nullptr;  // the device's own triangle BVHs (NODE_TRIBVH) and their triangles in leaf order
+    DWTri *btris = nullptr;
+    uint32_t n_bvh2 = 0, n_btris = 0;
     uint32_t *quick = nullptr; // LDS records of the first top-level leaves (rtmi_device.hpp stage_scene)
     uint32_t n_quick = 0;
     DScene<float> h32;
@@ -372,9 +386,9 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
 
 // World-space copies of the triangle leaves (DWTri, f32 path) in the order upload_typed numbers them (device leaf order),
 // and the NODE_ALLTRI marking of the nodes whose direct leaves are all triangles.
-static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout &L) {
+static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout &L, std::vector<uint32_t> &tri_of_leaf) {
     std::vector<DWTri> out;
-    std::vector<uint32_t> tri_of_leaf(L.leaf_orig.size(), 0xFFFFFFFFu);
+    tri_of_leaf.assign(L.leaf_orig.size(), 0xFFFFFFFFu);
     for (size_t i = 0; i < L.leaf_orig.size(); ++i) {
         const rtmi_leaf &s = d->leaves[L.leaf_orig[i]];
         if (s.kind != RTMI_TRIANGLE && s.kind != RTMI_SMOOTH_TRIANGLE) continue;
@@ -411,6 +425,187 @@ static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout
         if (all) { nd.flags |= NODE_ALLTRI; nd.csg_count = tri_of_leaf[nd.leaf_first]; }
     }
     return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: the device's own triangle BVH (DBvh2, rtmi_device.hpp) below every maximal all-triangle subtree
+// ---------------------------------------------------------------------------------------------
+struct TriBvhBuilder {
+    struct Box {
+        float lo[3], hi[3];
+        void clear() { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
+        void add(const Box &b) { for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], b.lo[a]); hi[a] = std::fmax(hi[a], b.hi[a]); } }
+        double area() const {
+            const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+            return x < 0 ? 0.0 : 2.0 * (x * y + y * z + z * x);
+        }
+    };
+    struct Item { Box b; float c[3]; uint32_t wtri, leaf; };
+    struct Bin2 { Box b; int left = -1, right = -1; uint32_t first = 0, count = 0; }; // binary tree: inner (left, right) or leaf (first, count)
+    std::vector<Item> items;
+    std::vector<Bin2> bin;
+    std::vector<DBvh2> &out2;
+    std::vector<DWTri> &out_tris;
+    const std::vector<DWTri> &wtris;
+    int leaf_max;
+    int depth = 0;
+
+    TriBvhBuilder(std::vector<DBvh2> &o2, std::vector<DWTri> &ot, const std::vector<DWTri> &w, int lm) : out2(o2), out_tris(ot), wtris(w), leaf_max(lm) {}
+
+    // bounds of a world-space triangle as the device sees it (float corners), padded like the scene nodes' boxes
+    static Box tri_box(const DWTri &w) {
+        Box b;
+        for (int a = 0; a < 3; ++a) {
+            const double v0 = w.p1[a], v1 = (double)w.p1[a] + w.e1[a], v2 = (double)w.p1[a] + w.e2[a];
+            const double lo = std::fmin(v0, std::fmin(v1, v2)), hi = std::fmax(v0, std::fmax(v1, v2));
+            const double pad = 1e-5 * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo) + 1e-6;
+            float flo = (float)(lo - pad), fhi = (float)(hi + pad);
+            if ((double)flo > lo - pad) flo = std::nextafterf(flo, -INFINITY);
+            if ((double)fhi < hi + pad) fhi = std::nextafterf(fhi, INFINITY);
+            b.lo[a] = flo; b.hi[a] = fhi;
+        }
+        return b;
+    }
+
+    void add(uint32_t wtri, uint32_t leaf) {
+        Item it;
+        it.b = tri_box(wtris[wtri]);
+        for (int a = 0; a < 3; ++a) it.c[a] = 0.5f * (it.b.lo[a] + it.b.hi[a]);
+        it.wtri = wtri; it.leaf = leaf;
+        items.push_back(it);
+    }
+
+    // binned surface-area heuristic, 16 bins on the axis where the centres spread most; a median split when that fails
+    int build2(uint32_t first, uint32_t count) {
+        const int me = (int)bin.size();
+        bin.emplace_back();
+        Box b; b.clear();
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = first; i < first + count; ++i) {
+            b.add(items[i].b);
+            for (int a = 0; a < 3; ++a) { clo[a] = std::fmin(clo[a], items[i].c[a]); chi[a] = std::fmax(chi[a], items[i].c[a]); }
+        }
+        bin[me].b = b; bin[me].first = first; bin[me].count = count;
+        if (count <= 1) return me;
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+        const float ext = chi[axis] - clo[axis];
+        uint32_t mid = first + count / 2;
+        bool split = false;
+        if (ext > 0 && std::isfinite(ext)) {
+            constexpr int NB = 16;
+            Box bb[NB]; uint32_t bn[NB] = {};
+            for (auto &x : bb) x.clear();
+            const float scale = (float)NB / ext;
+            auto bin_of = [&](const Item &it) { int k = (int)((it.c[axis] - clo[axis]) * scale); return k < 0 ? 0 : (k >= NB ? NB - 1 : k); };
+            for (uint32_t i = first; i < first + count; ++i) { const int k = bin_of(items[i]); bb[k].add(items[i].b); ++bn[k]; }
+            double best = INFINITY; int best_k = -1;
+            Box acc; double la[NB]; uint32_t ln[NB];
+            acc.clear(); uint32_t n = 0;
+            for (int k = 0; k < NB - 1; ++k) { acc.add(bb[k]); n += bn[k]; la[k] = acc.area(); ln[k] = n; }
+            acc.clear(); n = 0;
+            for (int k = NB - 1; k > 0; --k) {
+                acc.add(bb[k]); n += bn[k];
+                if (ln[k - 1] == 0 || n == 0) continue;
+                const double cost = la[k - 1] * ln[k - 1] + acc.area() * n;
+                if (cost < best) { best = cost; best_k = k; }
+            }
+            const double leaf_cost = b.area() * count;
+            if (best_k > 0 && (count > (uint32_t)leaf_max || best + 0.5 * b.area() < leaf_cost)) {
+                auto it = std::partition(items.begin() + first, items.begin() + first + count, [&](const Item &x) { return bin_of(x) < best_k; });
+                mid = (uint32_t)(it - items.begin());
+                split = mid > first && mid < first + count;
+            }
+        }
+        if (!split) {
+            if (count <= (uint32_t)leaf_max) return me; // a leaf
+            mid = first + count / 2;                      // coincident centres: any split will do
+            std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + first + count,
+                             [&](const Item &x, const Item &y) { return x.c[axis] < y.c[axis]; });
+        }
+        const int l = build2(first, mid - first);
+        const int r = build2(mid, first + count - mid);
+        bin[me].left = l; bin[me].right = r;
+        return me;
+    }
+
+    uint32_t leaf_entry(const Bin2 &n) const { return ENT_TRIS | ((n.count - 1u) << ENT_TRI_FIRST_BITS) | (tri_base + n.first); }
+    uint32_t tri_base = 0;
+
+    // one DBvh2 record per inner node: both children's boxes and entries
+    uint32_t emit2(int node, int d) {
+        depth = std::max(depth, d);
+        const Bin2 &n = bin[node];
+        if (n.left < 0) return leaf_entry(n);
+        const uint32_t me = (uint32_t)out2.size();
+        out2.emplace_back();
+        DBvh2 rec;
+        memset(&rec, 0, sizeof rec);
+        for (int a = 0; a < 3; ++a) {
+            rec.lo0[a] = bin[n.left].b.lo[a]; rec.hi0[a] = bin[n.left].b.hi[a];
+            rec.lo1[a] = bin[n.right].b.lo[a]; rec.hi1[a] = bin[n.right].b.hi[a];
+        }
+        rec.child[0] = emit2(n.left, d + 1);
+        rec.child[1] = emit2(n.right, d + 1);
+        out2[me] = rec;
+        return ENT_BVH | me;
+    }
+
+    // builds the tree over the items added so far and returns the stack entry of its root
+    uint32_t finish() {
+        if ((size_t)out_tris.size() + items.size() > (size_t)ENT_TRI_FIRST_MASK) return 0;
+        tri_base = (uint32_t)out_tris.size();
+        const int root = build2(0, (uint32_t)items.size());
+        for (const Item &it : items) { DWTri w = wtris[it.wtri]; w.pad = it.leaf; out_tris.push_back(w); }
+        return emit2(root, 1);
+    }
+};
+
+// Marks every maximal subtree of Groups / BoundingGroups that holds nothing but (usable) triangles NODE_TRIBVH and builds
+// its DBvh2 tree.  `tri_of_leaf`: device leaf -> index into wtris (or none).  Returns the deepest tree's depth in nodes.
+static int build_triangle_bvhs(Layout &L, const std::vector<DWTri> &wtris, const std::vector<uint32_t> &tri_of_leaf, std::vector<DBvh2> &bvh2,
+                               std::vector<DWTri> &btris, std::vector<int> &bvh_depth_of_node) {
+    const long leaf_max = std::max(1l, std::min((long)BVH_LEAF_MAX, env_long("RTMI_BVH_LEAF", RTMI_BVH_LEAF)));
+    bvh_depth_of_node.assign(L.nodes.size(), 0);
+    // all_tri[n]: node n's whole subtree is triangles that have a world-space record, under properly boxed nodes
+    std::vector<int8_t> all_tri(L.nodes.size(), -1);
+    std::function<bool(uint32_t)> scan = [&](uint32_t n) -> bool {
+        const DNode &nd = L.nodes[n];
+        bool ok = !(nd.flags & NODE_CSGROOT) && (nd.flags & NODE_GATED) && (nd.leaf_count + nd.child_count) > 0;
+        for (uint32_t i = 0; i < nd.leaf_count; ++i) {
+            const uint32_t t = tri_of_leaf[nd.leaf_first + i];
+            if (t == 0xFFFFFFFFu || !std::isfinite(wtris[t].k) || wtris[t].k == 0.0f) ok = false;
+        }
+        for (uint32_t c = 0; c < nd.child_count; ++c) ok = scan(nd.child_first + c) && ok; // (scan every child: the marks are used below)
+        all_tri[n] = ok ? 1 : 0;
+        return ok;
+    };
+    for (uint32_t c = 0; c < L.nodes[0].child_count; ++c) scan(L.nodes[0].child_first + c);
+    int deepest = 0;
+    std::function<void(uint32_t, TriBvhBuilder &)> gather = [&](uint32_t n, TriBvhBuilder &b) {
+        const DNode &nd = L.nodes[n];
+        for (uint32_t i = 0; i < nd.leaf_count; ++i) b.add(tri_of_leaf[nd.leaf_first + i], nd.leaf_first + i);
+        for (uint32_t c = 0; c < nd.child_count; ++c) gather(nd.child_first + c, b);
+    };
+    std::function<void(uint32_t)> mark = [&](uint32_t n) {
+        DNode &nd = L.nodes[n];
+        if (all_tri[n] == 1) {
+            TriBvhBuilder b(bvh2, btris, wtris, (int)leaf_max);
+            gather(n, b);
+            const uint32_t entry = b.items.size() >= 4 ? b.finish() : 0u; // (a handful of triangles: the reference's node will do)
+            if (entry && b.depth < PACKET_STACK) {
+                nd.flags = (nd.flags | NODE_TRIBVH) & ~NODE_ALLTRI;
+                nd.csg_count = entry;
+                bvh_depth_of_node[n] = b.depth;
+                deepest = std::max(deepest, b.depth);
+                return;
+            }
+        }
+        if (!(nd.flags & NODE_CSGROOT))
+            for (uint32_t c = 0; c < nd.child_count; ++c) mark(nd.child_first + c);
+    };
+    for (uint32_t c = 0; c < L.nodes[0].child_count; ++c) mark(L.nodes[0].child_first + c);
+    return deepest;
 }
 
 template <typename R>
@@ -588,6 +783,9 @@ template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_d
     h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
     h.nodes = s->nodes; h.csgs = s->csgs; h.leaf_orig = s->leaf_orig;
     h.wtris = sizeof(R) == 4 ? s->wtris : nullptr;
+    h.bvh2 = sizeof(R) == 4 ? s->bvh2 : nullptr;
+    h.n_bvh2 = sizeof(R) == 4 ? s->n_bvh2 : 0u; h.n_btris = sizeof(R) == 4 ? s->n_btris : 0u;
+    h.btris = sizeof(R) == 4 ? s->btris : nullptr;
     h.n_leaves = (uint32_t)L.leaf_orig.size(); h.n_lights = (uint32_t)d->n_lights; h.n_nodes = (uint32_t)L.nodes.size();
     h.max_depth = (uint32_t)d->max_depth;
     h.root_leaf_count = L.nodes[0].leaf_count; h.root_child_first = L.nodes[0].child_first; h.root_child_count = L.nodes[0].child_count;
@@ -640,7 +838,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -660,9 +858,17 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     s->device = dev;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) s->num_cu = prop.multiProcessorCount;
-    std::vector<DWTri> wtris = world_space_triangles(desc, L);
+    std::vector<uint32_t> tri_of_leaf;
+    std::vector<DWTri> wtris = world_space_triangles(desc, L, tri_of_leaf);
+    std::vector<DBvh2> bvh2;
+    std::vector<DWTri> btris;
+    std::vector<int> bvh_depth;
+    build_triangle_bvhs(L, wtris, tri_of_leaf, bvh2, btris, bvh_depth);
     rc = upload(&s->nodes, L.nodes);
     if (rc == RTMI_OK) rc = upload(&s->wtris, wtris);
+    s->n_bvh2 = (uint32_t)bvh2.size(); s->n_btris = (uint32_t)btris.size();
+    if (rc == RTMI_OK) rc = upload(&s->bvh2, bvh2);
+    if (rc == RTMI_OK) rc = upload(&s->btris, btris);
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
     std::vector<uint32_t> quick;
@@ -737,11 +943,6 @@ static int check_camera(const rtmi_camera *c) {
 #ifndef RTMI_RESAMPLE_WAVES
 #define RTMI_RESAMPLE_WAVES 3 // waves per SIMD of the second pass's persistent grid
 #endif
-
-static long env_long(const char *name, long fallback) {
-    const char *e = getenv(name);
-    return e && *e ? atol(e) : fallback;
-}
 
 // RTMI_SPREAD_BELOW in the environment (read at every call) replaces the constant: 0 = never spread, a large number =
 // always; for the tests that hold both ways of the first pass against each other

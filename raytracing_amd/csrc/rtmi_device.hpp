@@ -57,6 +57,8 @@ constexpr uint32_t NODE_CSGROOT = 1u << 0;
 constexpr uint32_t NODE_GATED = 1u << 1;       // box is finite and proper: may be slab-tested
 constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
 constexpr uint32_t NODE_AXIS_SHIFT = 4;         // bits 4-5: 1 + the axis along which the node's two children are sorted by centre (0: no order)
+constexpr uint32_t NODE_TRIBVH = 1u << 6;      // f32 path: everything below this node is triangles (under Groups / BoundingGroups, no CSG) and has been
+                                               // rebuilt as a BVH of its own (DBvh2): csg_count = the entry of its root (ENT_BVH / ENT_TRIS)
 constexpr uint32_t NODE_ALLTRI = 1u << 3;      // not a CSG root, every direct leaf is a triangle: wtris[csg_count + i] is leaf
                                                // leaf_first + i in world space (f32 path)
 
@@ -109,6 +111,26 @@ struct DWTri { // 48 B
     uint32_t pad;
 };
 
+// The device's own BVH over the triangles below a NODE_TRIBVH node (f32 path).  The reference's tree - median splits on
+// centres down to ten triangles per BoundingGroup (shapes/mod.rs:489-563) - decides nothing about the image: the hit is
+// the nearest root over the LEAF SET, and a box only ever rules triangles out.  So the triangles are re-split on the
+// host (binned SAH, few triangles per leaf) into a binary tree whose nodes hold BOTH children's boxes in one 64-byte
+// record, and a wave walks that tree TOGETHER (packet_tris): one shared stack, node and triangle records through
+// scalar loads, every lane testing its own ray against the same box or triangle.  The rays of a wave - an 8x8 tile's
+// primary rays, the samples of one pixel, shadow rays towards one light - are a narrow bundle, so the union of the
+// nodes they need is close to what each needs alone; and a traversal without per-lane stacks, vector loads or
+// divergent branches is what this machine runs well.
+struct alignas(64) DBvh2 { // 64 B
+    float lo0[3], hi0[3], lo1[3], hi1[3]; // the two children's bounds
+    uint32_t child[2];                     // stack entries (ENT_BVH | node, ENT_TRIS | count - 1 << 26 | first triangle)
+    uint32_t pad[2];
+};
+// entries: bit 31 set = something of a DBvh2 tree (scene node indices have it clear)
+constexpr uint32_t ENT_BVH = 0x80000000u, ENT_TRIS = 0xC0000000u, ENT_KIND = 0xC0000000u;
+constexpr uint32_t ENT_TRI_FIRST_BITS = 26, ENT_TRI_FIRST_MASK = (1u << ENT_TRI_FIRST_BITS) - 1u;
+constexpr int BVH_LEAF_MAX = 8;   // triangles per DBvh2 leaf (3 bits of count - 1 are used of the 4 available)
+constexpr int PACKET_STACK = 64;  // entries of the wave's shared stack (the host checks the trees' depth against it)
+
 struct DNode { // 48 B
     float bmin[3];
     uint32_t leaf_first;
@@ -136,6 +158,9 @@ template <typename R> struct DScene {
     const DCsg *csgs;
     const uint32_t *leaf_orig; // device leaf -> index in rtmi_scene_desc.leaves
     const DWTri *wtris;        // one per entry of tris (f32 scene only, else null)
+    const DBvh2 *bvh2;         // the NODE_TRIBVH trees (f32 scene only)
+    const DWTri *btris;        // their triangles in leaf order, pad = the device leaf
+    uint32_t n_bvh2, n_btris;  // (what packet_tris checks its entries against)
     uint32_t n_leaves, n_lights, n_nodes, max_depth;
     uint32_t root_leaf_count, root_child_first, root_child_count, pad;
     // what stage_scene copies into LDS (f32 scene only, else null / 0)
@@ -615,7 +640,7 @@ template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op
 // buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
 // its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
 template <typename R, int MODE>
-__device__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
+__device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
                          Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     R bt[CSG_BUF];
     uint32_t bid[CSG_BUF];
@@ -797,8 +822,100 @@ __device__ __forceinline__ void tri_leaf(const DWTri &w, uint32_t li, const Ray<
         const bool front = hit && ((li == hit_leaf) ? (0u < hit_ord) : (t < t_limit));
         if (li == hit_leaf) open.hit_parity = front ? 1u : 0u;
         if (front) open_candidate(open, li, hit_leaf, t);
-    } else if (hit && t >= 0.0f && t < t_limit && t < best.t) {
+    } else if (hit && t >= 0.0f && t < t_limit && (t < best.t || (t == best.t && li < best.leaf))) {
+        // (equal roots - a ray through an edge two triangles share - go to the lower leaf whatever order the triangles
+        // are met in: a wave that walks the tree together meets them in an order that depends on its other rays)
         best.t = t; best.leaf = li; best.ord = 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A wave walks a DBvh2 tree together (f32 path).  `mine`: this lane's ray needs the tree (it passed the NODE_TRIBVH node's
+// own box).  Everything that steers the walk is wave-uniform: the current entry, the shared stack (LDS, one per wave;
+// each entry carries the mask of the lanes whose ray hit that node's box), the node and triangle records (scalar loads).
+// A lane tests a node's child boxes only if it hit the node itself - exactly the tests it would make walking alone,
+// which is also what the counters count - and a subtree is entered if any lane's ray can still find a root in it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t (*lds_packet_stack())[PACKET_STACK] {
+    __shared__ uint32_t s_packet[3][PACKET_STACK]; // entry, mask low, mask high
+    return s_packet;
+}
+__device__ __forceinline__ bool slab2(const float *lo, const float *hi, const Ray<float> &ray, V3<float> inv_d, float t_lo, float t_hi, float &tnear) {
+    // (NaN-ignoring min / max: a ray that runs inside a slab's boundary plane counts as inside the slab)
+    const float x0 = (lo[0] - ray.o.x) * inv_d.x, x1 = (hi[0] - ray.o.x) * inv_d.x;
+    const float y0 = (lo[1] - ray.o.y) * inv_d.y, y1 = (hi[1] - ray.o.y) * inv_d.y;
+    const float z0 = (lo[2] - ray.o.z) * inv_d.z, z1 = (hi[2] - ray.o.z) * inv_d.z;
+    const float tmin = max_(max_(min_(x0, x1), min_(y0, y1)), min_(z0, z1));
+    const float tmax = min_(min_(max_(x0, x1), max_(y0, y1)), max_(z0, z1));
+    tnear = tmin;
+    return tmin <= tmax && tmin <= t_hi && tmax >= t_lo;
+}
+template <int MODE>
+__device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t root, bool mine, const Ray<float> &ray, V3<float> inv_d, uint32_t origin_leaf,
+                            uint32_t origin_side, Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
+    uint32_t (*stk)[PACKET_STACK] = lds_packet_stack();
+#ifdef RTMI_HOST_EMUL
+    const int lane = 0; // (the emulation runs one lane at a time: a wave of one)
+#else
+    const int lane = threadIdx.x & 63;
+#endif
+    // the lane that writes the shared stack: the first lane that is here at all (lane 0 may not be - its pixel finished,
+    // its ray hit nothing - and a push nobody made would be popped as whatever the LDS held)
+    const int writer = __ffsll((long long)__ballot(true)) - 1;
+    uint32_t cur = root;
+    unsigned long long mask = __ballot(mine);
+    int sp = 0;
+    const float lo = (MODE == MODE_COLLECT) ? -Lim<float>::inf() : 0.0f;
+    for (;;) {
+        const bool in = (mask >> lane) & 1ull;
+        bool pop = false;
+        if ((cur & ENT_KIND) == ENT_TRIS) {
+            const uint32_t first = cur & ENT_TRI_FIRST_MASK, count = ((cur >> ENT_TRI_FIRST_BITS) & 15u) + 1u;
+            if (first + count > sc.n_btris) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: an entry that is not the builder's must not become an address)
+            if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
+                for (uint32_t i = 0; i < count; ++i) {
+                    const DWTri &w = sc.btris[first + i]; // (wave-uniform index: a scalar load)
+                    tri_leaf<MODE>(w, w.pad, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+                }
+            }
+            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return; // every ray of the wave is shadowed
+            pop = true;
+        } else {
+            if (!(cur & ENT_BVH) || (cur & ~ENT_KIND) >= sc.n_bvh2) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            const DBvh2 &n = sc.bvh2[cur & ~ENT_KIND];
+            const float hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
+            float t0 = 0, t1 = 0;
+            bool h0 = false, h1 = false;
+            if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
+                h0 = slab2(n.lo0, n.hi0, ray, inv_d, lo, hi, t0);
+                h1 = slab2(n.lo1, n.hi1, ray, inv_d, lo, hi, t1);
+                st.c[RTMI_STAT_NODE_VISITS]++;
+                st.c[RTMI_STAT_AABB_TESTS] += 2;
+                st.flops += 2 * F_AABB;
+            }
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            if ((m0 | m1) == 0ull) pop = true;
+            else if (m0 == 0ull) { cur = n.child[1]; mask = m1; }
+            else if (m1 == 0ull) { cur = n.child[0]; mask = m0; }
+            else {
+                // both: the child most rays meet first goes first (closest hit: what it finds prunes the other)
+                const bool one_first = MODE == MODE_CLOSEST && __popcll(__ballot(h0 && h1 && t1 < t0)) * 2 > __popcll(m0 & m1);
+                const uint32_t far = one_first ? n.child[0] : n.child[1];
+                const unsigned long long fm = one_first ? m0 : m1;
+                if (sp < PACKET_STACK) { // (the host checks the depth: always true)
+                    if (lane == writer) { stk[0][sp] = far; stk[1][sp] = (uint32_t)fm; stk[2][sp] = (uint32_t)(fm >> 32); }
+                    ++sp;
+                } else st.c[RTMI_STAT_OVERFLOW] = 1;
+                cur = one_first ? n.child[1] : n.child[0];
+                mask = one_first ? m1 : m0;
+            }
+        }
+        if (pop) {
+            if (sp == 0) return;
+            --sp;
+            cur = __builtin_amdgcn_readfirstlane(stk[0][sp]);
+            mask = (unsigned long long)__builtin_amdgcn_readfirstlane(stk[1][sp]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(stk[2][sp]) << 32);
+        }
     }
 }
 
@@ -815,7 +932,7 @@ __device__ __forceinline__ uint32_t (*lds_node_stack())[64] {
 //   MODE_ANY    : best.leaf != NONE iff some shadow-casting root lies in [0, t_limit)
 //   MODE_COLLECT: open = which leaves the ray is inside of just in front of (t_limit, hit_leaf, hit_ord)
 template <typename R, int MODE, bool TREE>
-__device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
+__device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     // Top-level primitives: wave-uniform loop bounds.  f32: the first n_quick of them have a record in the LDS block
     // (stage_scene), fetched one leaf ahead of its test; LEAF_QUICK ones need nothing else, the others go on to their
@@ -866,39 +983,63 @@ __device__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin
     // "while-while" traversal: every lane first walks inner nodes until it holds a node with leaves (lanes that found one
     // wait for the others), then the wave tests leaves together - instead of lanes at inner nodes idling through their
     // neighbours' triangle loops.
+    constexpr uint32_t W_PACKET = 0x80000000u; // (w_flags) the batch is a whole DBvh2 tree: w_first = its root entry
+    auto push = [&](uint32_t v) {
+        if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
+        else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
+        else st.c[RTMI_STAT_OVERFLOW] = 1;
+    };
     for (;;) {
         uint32_t w_first = 0, w_count = 0, w_flags = 0, w_aux = 0;
         bool have = false;
         while (sp > 0 && !have) {
             --sp;
             const uint32_t top = sp < LDS_NODES ? lds[sp][lane] : deep[sp - LDS_NODES];
+            // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its
+            // negative-t roots for the in/out state); collect: anything in front of the hit counts
+            const R hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
+            const R lo = (MODE == MODE_COLLECT) ? -Lim<R>::inf() : (R)0;
             const DNode nd = sc.nodes[top];
             if (MODE == MODE_ANY && !(nd.flags & NODE_CAST_SHADOW)) continue;
             if (nd.flags & NODE_GATED) {
-                // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its
-                // negative-t roots for the in/out state); collect: anything in front of the hit counts
-                R hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
-                R lo = (MODE == MODE_COLLECT) ? -Lim<R>::inf() : (R)0;
                 st.c[RTMI_STAT_AABB_TESTS]++;
                 st.flops += F_AABB;
                 if (!slab(nd, ray, inv_d, lo, hi)) continue;
             }
             st.c[RTMI_STAT_NODE_VISITS]++;
+            if constexpr (sizeof(R) == 4) {
+                if (nd.flags & NODE_TRIBVH) { // everything below is the device's own tree, which the wave walks together
+                    w_first = nd.csg_count; w_flags = W_PACKET;
+                    have = true;
+                    continue;
+                }
+            }
             if (!(nd.flags & NODE_CSGROOT)) {
                 // children are popped first to last; sorted children (two, by centre along an axis) last to first when the
                 // ray runs down that axis: the nearer one first
                 const uint32_t ax = (nd.flags >> NODE_AXIS_SHIFT) & 3u;
                 const bool rev = ax != 0 && (ax == 1 ? ray.d.x : ax == 2 ? ray.d.y : ray.d.z) < (R)0;
-                for (uint32_t c = nd.child_count; c-- > 0;) {
-                    const uint32_t v = nd.child_first + (rev ? nd.child_count - 1u - c : c);
-                    if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
-                    else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
-                    else st.c[RTMI_STAT_OVERFLOW] = 1;
-                }
+                for (uint32_t c = nd.child_count; c-- > 0;) push(nd.child_first + (rev ? nd.child_count - 1u - c : c));
             }
             if ((nd.flags & NODE_CSGROOT) || nd.leaf_count) {
                 w_first = nd.leaf_first; w_count = nd.leaf_count; w_flags = nd.flags; w_aux = nd.csg_count;
                 have = true;
+            }
+        }
+        if constexpr (sizeof(R) == 4) {
+            // the lanes that came to a DBvh2 tree walk it together, one tree after the other if they hold different ones
+            // (every lane of the wave is here: those without a batch just do not take part)
+            unsigned long long pend = __ballot(have && w_flags == W_PACKET);
+            while (pend) {
+                const int leader = __ffsll((long long)pend) - 1;
+                const uint32_t root = __builtin_amdgcn_readlane(w_first, leader);
+                const bool mine = have && w_flags == W_PACKET && w_first == root;
+                packet_tris<MODE>(sc, root, mine, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+                pend &= ~__ballot(mine);
+            }
+            if (have && w_flags == W_PACKET) {
+                if (MODE == MODE_ANY && best.leaf != NONE) return;
+                continue;
             }
         }
         if (!have) break;
@@ -1211,7 +1352,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
 // shade_hit is linear in its children's colours, so each ray carries the product of the factors
 // above it ("weight") and adds weight * (clipped direct light + emissive) to the sample.
 template <typename R, bool TREE>
-__device__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
+__device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
     const R EPS = (R)RTMI_EPSILON;
     V3<R> acc = mk<R>(0, 0, 0);
     R weight = (R)1;

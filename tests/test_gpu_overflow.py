@@ -1,9 +1,7 @@
-"""The adaptive second pass with a work-queue slot far too small for the frame (RTMI_WORK_MB).  While the two queues
-still hold every unconverged pixel, unit lists and the heavy table may overflow as they like: the image and the ray
-counters stay what they are with room to spare, bit for bit (the chunking of a pixel's samples never depends on who
-computes them).  When the queues themselves overflow, the lanes left without a slot finish their pixels alone, sample
-by sample like the reference: the same stopping rule on sums added in another order, so the frame agrees closely
-but not bit for bit.
+"""The adaptive second pass with a work-queue slot far too small for the frame (RTMI_WORK_MB).  Queues, unit
+lists and the heavy table may overflow as they like: the image and the ray counters stay what they are with room to
+spare, bit for bit - a pixel's sums are the reference's sequential ones (camera.rs:285-286) wherever its samples are
+taken, also on the lanes that find no queue slot and finish their pixels alone.
 
 The same comparison guards something a build could lose silently: a sample's colour must not depend on which kernel
 computes it (resample_kernel in rounds, units_kernel in units), although the compiler is free to fuse multiply-adds
@@ -52,22 +50,26 @@ def _render(work_mb):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
+RAYS = slice(0, 5)  # primary, reflection, refraction, shadow, samples
+
+
+def _same(a, b, scene):
+    assert a[scene]["sha"] == b[scene]["sha"], scene
+    if scene == "teapot":  # a wave walks the triangle BVH together: the work counters depend on the schedule, the rays do not
+        assert a[scene]["stats"][RAYS] == b[scene]["stats"][RAYS], scene
+    else:
+        assert a[scene]["stats"] == b[scene]["stats"], scene
+
+
 def test_small_work_slots_change_nothing():
     full = _render(0)
-    # 2 MiB: 10922 pixels per queue, 360 units per pass.  The small frames' queues fit; their unit lists do not.
+    # 2 MiB: 10922 pixels per queue, 360 units per pass.  The small frames' queues fit; their unit lists do not.  The
+    # 1280x720 frame queues many times that: the rest are finished by their first-pass lanes, sample by sample - the
+    # same sequential sums (camera.rs:285-286), so the frame is the same bit for bit there too.
     small = _render(2)
-    for scene in ("ch11a", "ch11a_f64", "soft", "dice", "teapot"):
-        assert small[scene]["sha"] == full[scene]["sha"], scene
-        assert small[scene]["stats"] == full[scene]["stats"], scene
-    # ... the 1280x720 frame queues three times that many pixels: the rest are finished by their first-pass lanes
-    import numpy as np
-    a, b = np.array(small["ch11a_big"]["coarse"]), np.array(full["ch11a_big"]["coarse"])
-    assert np.abs(a - b).max() < 0.02
-    sa, sb = small["ch11a_big"]["stats"], full["ch11a_big"]["stats"]
-    i = 4  # samples
-    assert abs(sa[i] - sb[i]) < 0.01 * sb[i]
+    for scene in full:
+        _same(small, full, scene)
     # 16 MiB: every queue fits again, the unit lists (2900 units) overflow on the big frame
     mid = _render(16)
     for scene in full:
-        assert mid[scene]["sha"] == full[scene]["sha"], scene
-        assert mid[scene]["stats"] == full[scene]["stats"], scene
+        _same(mid, full, scene)

@@ -33,11 +33,14 @@ def _both(world, cam, **opts):
     return res
 
 
-def _same(res):
+RAY_KEYS = ("primary", "reflection", "refraction", "shadow", "samples", "overflow")
+
+
+def _same(res, keys=KEYS):
     (a, sa), (b, sb) = res
     assert np.isfinite(b).all() and (b >= 0).all()
     assert np.array_equal(a, b)
-    for k in KEYS:
+    for k in keys:
         assert sa[k] == sb[k], k
     assert sb["overflow"] == 0
     return sb
@@ -49,7 +52,9 @@ def test_two_calls_in_a_row_the_second_smaller():
     st = _same(_both(*scenes.chapter11a(640, 360), seed=5))
     assert st["samples"] > 12 * 640 * 360
     # 2: a smaller frame of another scene (tree traversal, area of the array used before is now stale)
-    st = _same(_both(*scenes.chapter15(200, 120, lite=True), seed=6))
+    # (a triangle mesh: a wave walks its BVH together, so the work counters depend on how the queues - of another size
+    # here - group the samples; image and rays do not)
+    st = _same(_both(*scenes.chapter15(200, 120, lite=True), seed=6), RAY_KEYS)
     assert st["samples"] > 12 * 200 * 120
     # 3: f64 validation mode, and a row-tile share
     _same(_both(*scenes.soft_shadow(256, 128), seed=7, precision=1))
