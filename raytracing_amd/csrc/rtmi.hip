@@ -864,6 +864,18 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     std::vector<DWTri> btris;
     std::vector<int> bvh_depth;
     build_triangle_bvhs(L, wtris, tri_of_leaf, bvh2, btris, bvh_depth);
+    {   // the wave's shared stack (packet_scene / packet_tris, f32 path): siblings that wait while a child is walked, plus
+        // one entry per level of a triangle BVH below
+        std::function<int(uint32_t)> need = [&](uint32_t slot) -> int {
+            const DNode &o = L.nodes[slot];
+            if (o.flags & NODE_CSGROOT) return 0;
+            if (o.flags & NODE_TRIBVH) return bvh_depth[slot];
+            int n = (int)o.child_count;
+            for (uint32_t i = 0; i < o.child_count; ++i) n = std::max(n, (int)(o.child_count - 1 - i) + need(o.child_first + i));
+            return n;
+        };
+        if (need(0) > PACKET_STACK) { delete s; return fail(RTMI_ERR_UNSUPPORTED, "scene tree needs a deeper traversal stack than " + std::to_string(PACKET_STACK)); }
+    }
     rc = upload(&s->nodes, L.nodes);
     if (rc == RTMI_OK) rc = upload(&s->wtris, wtris);
     s->n_bvh2 = (uint32_t)bvh2.size(); s->n_btris = (uint32_t)btris.size();

@@ -851,8 +851,9 @@ __device__ __forceinline__ bool slab2(const float *lo, const float *hi, const Ra
     return tmin <= tmax && tmin <= t_hi && tmax >= t_lo;
 }
 template <int MODE>
-__device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t root, bool mine, const Ray<float> &ray, V3<float> inv_d, uint32_t origin_leaf,
+__device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t root, bool mine, int base, const Ray<float> &ray, V3<float> inv_d, uint32_t origin_leaf,
                             uint32_t origin_side, Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
+    // (base: the entries of the shared stack below it belong to the caller, packet_scene)
     uint32_t (*stk)[PACKET_STACK] = lds_packet_stack();
 #ifdef RTMI_HOST_EMUL
     const int lane = 0; // (the emulation runs one lane at a time: a wave of one)
@@ -864,7 +865,7 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
     const int writer = __ffsll((long long)__ballot(true)) - 1;
     uint32_t cur = root;
     unsigned long long mask = __ballot(mine);
-    int sp = 0;
+    int sp = base;
     const float lo = (MODE == MODE_COLLECT) ? -Lim<float>::inf() : 0.0f;
     for (;;) {
         const bool in = (mask >> lane) & 1ull;
@@ -911,10 +912,80 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
             }
         }
         if (pop) {
-            if (sp == 0) return;
+            if (sp == base) return;
             --sp;
             cur = __builtin_amdgcn_readfirstlane(stk[0][sp]);
             mask = (unsigned long long)__builtin_amdgcn_readfirstlane(stk[1][sp]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(stk[2][sp]) << 32);
+        }
+    }
+}
+
+// The scene tree below World::objects (Groups, BoundingGroups, CSG roots, triangle meshes), walked by the whole wave together
+// like packet_tris (f32 path): one shared stack of node indices, node and leaf records through scalar loads.  A node is
+// entered if any lane's ray passes its box (aabb.rs:45-70 on the padded f32 box) and can still find a root there; only
+// those lanes test its leaves, evaluate its CSG tree or go on into its triangle BVH.
+template <int MODE>
+__device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<float> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<float> &best,
+                                             float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
+    uint32_t (*stk)[PACKET_STACK] = lds_packet_stack();
+#ifdef RTMI_HOST_EMUL
+    const int lane = 0;
+#else
+    const int lane = threadIdx.x & 63;
+#endif
+    const int writer = __ffsll((long long)__ballot(true)) - 1; // (see packet_tris)
+    const V3<float> inv_d = mk<float>(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+    const float lo = (MODE == MODE_COLLECT) ? -Lim<float>::inf() : 0.0f;
+    int sp = 0;
+    auto push = [&](uint32_t v) {
+        if (sp < PACKET_STACK) { if (lane == writer) stk[0][sp] = v; ++sp; }
+        else st.c[RTMI_STAT_OVERFLOW] = 1; // (the host checks the tree's need against PACKET_STACK: never)
+    };
+    for (uint32_t c = sc.root_child_count; c-- > 0;) push(sc.root_child_first + c); // popped first to last
+    while (sp > 0) {
+        if (MODE == MODE_ANY && __ballot(best.leaf == NONE) == 0ull) return; // every ray of the wave is shadowed
+        --sp;
+        const uint32_t top = __builtin_amdgcn_readfirstlane(stk[0][sp]);
+        if (top >= sc.n_nodes) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: a stack entry must not become an address unchecked)
+        const DNode &nd = sc.nodes[top];
+        const uint32_t flags = nd.flags;
+        if (MODE == MODE_ANY && !(flags & NODE_CAST_SHADOW)) continue;
+        // closest / any: some root with 0 <= t <= hi must be possible (a CSG root then still evaluates its negative-t
+        // roots for the in/out state); collect: anything in front of the hit counts
+        const float hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
+        bool h = !(MODE == MODE_ANY && best.leaf != NONE);
+        if ((flags & NODE_GATED) && h) {
+            st.c[RTMI_STAT_AABB_TESTS]++;
+            st.flops += F_AABB;
+            h = slab(nd, ray, inv_d, lo, hi);
+        }
+        const unsigned long long hm = __ballot(h);
+        if (hm == 0ull) continue;
+        if (h) st.c[RTMI_STAT_NODE_VISITS]++;
+        if (flags & NODE_TRIBVH) {
+            packet_tris<MODE>(sc, nd.csg_count, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            continue;
+        }
+        if (flags & NODE_CSGROOT) {
+            if (h) csg_root<float, MODE>(sc, nd.leaf_first, nd.leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            continue;
+        }
+        // children are popped first to last; sorted children (two, by centre along an axis) last to first when most of the
+        // rays run down that axis: the nearer one first
+        const uint32_t ax = (flags >> NODE_AXIS_SHIFT) & 3u, n_children = nd.child_count, child_first = nd.child_first;
+        bool rev = false;
+        if (ax != 0) rev = __popcll(__ballot(h && (ax == 1 ? ray.d.x : ax == 2 ? ray.d.y : ray.d.z) < 0.0f)) * 2 > __popcll(hm);
+        for (uint32_t c = n_children; c-- > 0;) push(child_first + (rev ? n_children - 1u - c : c));
+        const uint32_t leaf_first = nd.leaf_first, leaf_count = nd.leaf_count;
+        if (leaf_count && h) {
+            if (flags & NODE_ALLTRI) {
+                const uint32_t w0 = nd.csg_count;
+                for (uint32_t i = 0; i < leaf_count; ++i)
+                    tri_leaf<MODE>(sc.wtris[w0 + i], leaf_first + i, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            } else {
+                for (uint32_t li = leaf_first; li < leaf_first + leaf_count; ++li)
+                    plain_leaf<float, MODE>(sc, li, sc.leaves[li], sc.leaves[li].kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            }
         }
     }
 }
@@ -968,6 +1039,11 @@ __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray,
     }
     if (!TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
     if (sc.root_child_count == 0) return;
+    if constexpr (sizeof(R) == 4) { // the product path: the wave walks the tree together
+        packet_scene<MODE>(sc, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+        return;
+    }
+    // f64 validation mode: every lane walks the reference's tree on its own.
     // node stack: the first LDS_NODES entries of every lane in LDS ([entry][lane]), deeper ones in scratch
     uint32_t (*lds)[64] = lds_node_stack();
     const int lane = threadIdx.x & 63;
@@ -983,7 +1059,6 @@ __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray,
     // "while-while" traversal: every lane first walks inner nodes until it holds a node with leaves (lanes that found one
     // wait for the others), then the wave tests leaves together - instead of lanes at inner nodes idling through their
     // neighbours' triangle loops.
-    constexpr uint32_t W_PACKET = 0x80000000u; // (w_flags) the batch is a whole DBvh2 tree: w_first = its root entry
     auto push = [&](uint32_t v) {
         if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
         else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
@@ -1007,13 +1082,6 @@ __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray,
                 if (!slab(nd, ray, inv_d, lo, hi)) continue;
             }
             st.c[RTMI_STAT_NODE_VISITS]++;
-            if constexpr (sizeof(R) == 4) {
-                if (nd.flags & NODE_TRIBVH) { // everything below is the device's own tree, which the wave walks together
-                    w_first = nd.csg_count; w_flags = W_PACKET;
-                    have = true;
-                    continue;
-                }
-            }
             if (!(nd.flags & NODE_CSGROOT)) {
                 // children are popped first to last; sorted children (two, by centre along an axis) last to first when the
                 // ray runs down that axis: the nearer one first
@@ -1024,22 +1092,6 @@ __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray,
             if ((nd.flags & NODE_CSGROOT) || nd.leaf_count) {
                 w_first = nd.leaf_first; w_count = nd.leaf_count; w_flags = nd.flags; w_aux = nd.csg_count;
                 have = true;
-            }
-        }
-        if constexpr (sizeof(R) == 4) {
-            // the lanes that came to a DBvh2 tree walk it together, one tree after the other if they hold different ones
-            // (every lane of the wave is here: those without a batch just do not take part)
-            unsigned long long pend = __ballot(have && w_flags == W_PACKET);
-            while (pend) {
-                const int leader = __ffsll((long long)pend) - 1;
-                const uint32_t root = __builtin_amdgcn_readlane(w_first, leader);
-                const bool mine = have && w_flags == W_PACKET && w_first == root;
-                packet_tris<MODE>(sc, root, mine, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
-                pend &= ~__ballot(mine);
-            }
-            if (have && w_flags == W_PACKET) {
-                if (MODE == MODE_ANY && best.leaf != NONE) return;
-                continue;
             }
         }
         if (!have) break;

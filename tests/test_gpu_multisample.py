@@ -85,9 +85,9 @@ def test_frame_does_not_depend_on_the_schedule(name, kw, h, v, precision):
     assert ref_st["samples"] > 12 * h * v  # the open-ended loop does run (min_samples is 5 or 10)
     for pol, (img, st) in got.items():
         assert np.array_equal(img, ref_img), pol
-        # (the work counters too, except on triangle meshes: there a wave walks the device's BVH together and what a ray's
-        # running minimum prunes depends on the order its wave takes - the hits, and so the image and the rays, do not)
-        work = () if name == "teapot" else ("flops", "leaf_tests")
+        # (the work counters too, except on scenes with a tree: there a wave walks the tree together and what a ray's running
+        # minimum prunes depends on the order its wave takes - the hits, and so the image and the rays, do not)
+        work = () if name in ("teapot", "dice") else ("flops", "leaf_tests")
         for k in ("primary", "reflection", "refraction", "shadow", "samples", "overflow") + work:
             assert st[k] == ref_st[k], (pol, k)
 
