@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -603,9 +604,15 @@ struct ObjParser {
     std::vector<Vector> normals;
     std::map<std::string, Group> groups; // BTreeMap: ordered by name
     std::string current_group = "default_group";
+    // What the reference does with a `vt` (or `vp`) line is push it as a vertex - obj_loader.rs:35-36 matches any line
+    // that starts with "v" - which shifts every later vertex index; harmless for data/teapot.obj, whose `vt` block comes
+    // after its last `v`.  That behaviour is the default here too (drop-in); skip_texture_lines = true reads such files
+    // as OBJ means them.
+    bool skip_texture_lines = false;
 
-    static ObjParser parse_str(const std::string &input) { // obj_loader.rs:28-44
+    static ObjParser parse_str(const std::string &input, bool skip_texture_lines = false) { // obj_loader.rs:28-44
         ObjParser data;
+        data.skip_texture_lines = skip_texture_lines;
         data.groups["default_group"] = Group();
         std::istringstream in(input);
         std::string line;
@@ -613,6 +620,7 @@ struct ObjParser {
             size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n");
             line = b == std::string::npos ? "" : line.substr(b, e - b + 1);
             if (line.rfind("vn", 0) == 0) data.parse_normal(line);
+            else if (skip_texture_lines && (line.rfind("vt", 0) == 0 || line.rfind("vp", 0) == 0)) data.ignored_.push_back(line);
             else if (line.rfind("v", 0) == 0) data.parse_vertex(line); // NB: also catches "vt" like the reference (obj_loader.rs:36)
             else if (line.rfind("f", 0) == 0) data.parse_face(line);
             else if (line.rfind("g", 0) == 0) data.parse_group(line);
@@ -661,24 +669,48 @@ struct ObjParser {
         current_group = w.size() > 1 ? w[1] : "default_group";
         groups.emplace(current_group, Group());
     }
+    // An OBJ index: 1-based, or negative = counted back from the element defined last (-1 is the latest).  The reference
+    // parses into usize and knows only the first form (a negative index is dropped from a plain face, obj_loader.rs:113,
+    // and panics in a v/t/n one, :82); files that use the second form load here.
+    static bool parse_index(const std::string &s, size_t count, size_t &out) {
+        if (s.empty()) return false;
+        try {
+            size_t pos = 0;
+            const long long k = std::stoll(s, &pos);
+            if (pos != s.size()) return false;
+            if (k > 0) { out = (size_t)k - 1; return true; }
+            if (k < 0 && (size_t)(-k) <= count) { out = count - (size_t)(-k); return true; }
+        } catch (...) {}
+        return false;
+    }
     void parse_face(const std::string &line) { // obj_loader.rs:74-98
         auto el = words(line);
         el.erase(el.begin());
         if (el.empty()) throw std::runtime_error("obj: empty face");
         if (el[0].find('/') != std::string::npos) {
-            std::vector<std::pair<size_t, size_t>> idx;
+            std::vector<std::pair<size_t, size_t>> idx; // (vertex, normal); normal = npos for v/t elements
+            bool with_normals = true;
             for (auto &s : el) {
-                size_t a = s.find('/'), b = a == std::string::npos ? a : s.find('/', a + 1);
-                if (a == std::string::npos || b == std::string::npos) throw std::runtime_error("obj: face element needs v/t/n: " + s);
-                idx.push_back({(size_t)std::stoul(s.substr(0, a)) - 1, (size_t)std::stoul(s.substr(b + 1)) - 1});
+                const size_t a = s.find('/'), b = a == std::string::npos ? a : s.find('/', a + 1);
+                if (a == std::string::npos) throw std::runtime_error("obj: face element needs v/t/n: " + s);
+                size_t v = 0, n = std::string::npos;
+                if (!parse_index(s.substr(0, a), vertices.size(), v)) throw std::runtime_error("obj: bad vertex index in face element: " + s);
+                if (b == std::string::npos || b + 1 >= s.size()) with_normals = false; // "v/t": no normal (the reference panics here)
+                else if (!parse_index(s.substr(b + 1), normals.size(), n)) throw std::runtime_error("obj: bad normal index in face element: " + s);
+                idx.push_back({v, n});
             }
-            for (size_t i = 1; i + 1 < idx.size(); ++i) // triangulate_smooth_fan, obj_loader.rs:126-141
-                groups[current_group].add_child(smooth_triangle(vertices.at(idx[0].first), vertices.at(idx[i].first), vertices.at(idx[i + 1].first),
-                                                                normals.at(idx[0].second), normals.at(idx[i].second), normals.at(idx[i + 1].second)));
+            for (size_t i = 1; i + 1 < idx.size(); ++i) { // triangulate_smooth_fan, obj_loader.rs:126-141
+                if (with_normals)
+                    groups[current_group].add_child(smooth_triangle(vertices.at(idx[0].first), vertices.at(idx[i].first), vertices.at(idx[i + 1].first),
+                                                                    normals.at(idx[0].second), normals.at(idx[i].second), normals.at(idx[i + 1].second)));
+                else
+                    groups[current_group].add_child(triangle(vertices.at(idx[0].first), vertices.at(idx[i].first), vertices.at(idx[i + 1].first)));
+            }
         } else {
             std::vector<size_t> idx;
             for (auto &s : el) {
-                try { size_t pos = 0; unsigned long k = std::stoul(s, &pos); if (pos == s.size()) idx.push_back((size_t)k - 1); } catch (...) {}
+                size_t k = 0;
+                if (parse_index(s, vertices.size(), k)) idx.push_back(k); // (.filter_map(ok), obj_loader.rs:113)
             }
             for (size_t i = 1; i + 1 < idx.size(); ++i) // triangulate_fan, obj_loader.rs:112-124
                 groups[current_group].add_child(triangle(vertices.at(idx[0]), vertices.at(idx[i]), vertices.at(idx[i + 1])));
@@ -705,6 +737,60 @@ struct Canvas {
         std::vector<uint8_t> out(data.size() * 3);
         for (size_t i = 0; i < data.size(); ++i) data[i].to_u8(&out[3 * i]);
         return out;
+    }
+    // write_png (canvas.rs:95-110): 8-bit RGB, every pixel through Color::to_u8.  The reference hands the bytes to the png
+    // crate; here the file is written directly: signature, IHDR, one IDAT whose zlib stream holds the scanlines (filter
+    // type 0 in front of each) in stored deflate blocks - valid PNG, no compressor needed - and IEND.
+    std::vector<uint8_t> to_png() const {
+        const std::vector<uint8_t> rgb = to_rgb8();
+        std::vector<uint8_t> raw;
+        raw.reserve(((size_t)width_ * 3 + 1) * height_);
+        for (uint32_t y = 0; y < height_; ++y) {
+            raw.push_back(0);
+            raw.insert(raw.end(), rgb.begin() + (size_t)y * width_ * 3, rgb.begin() + (size_t)(y + 1) * width_ * 3);
+        }
+        std::vector<uint8_t> z = {0x78, 0x01}; // zlib header: deflate, 32 K window, no preset dictionary
+        uint32_t a = 1, b = 0;                  // Adler-32 of the raw bytes
+        size_t pos = 0;
+        do {
+            const size_t n = std::min<size_t>(65535, raw.size() - pos);
+            z.push_back(pos + n == raw.size() ? 1 : 0); // BFINAL, BTYPE = 00 (stored)
+            z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+            z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+            for (size_t i = 0; i < n; ++i) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+            z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+            pos += n;
+        } while (pos < raw.size());
+        const uint32_t adler = (b << 16) | a;
+        for (int k = 3; k >= 0; --k) z.push_back((uint8_t)(adler >> (8 * k)));
+        std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+        auto be32 = [](std::vector<uint8_t> &v, uint32_t x) { for (int k = 3; k >= 0; --k) v.push_back((uint8_t)(x >> (8 * k))); };
+        auto chunk = [&](const char *type, const std::vector<uint8_t> &body) {
+            be32(out, (uint32_t)body.size());
+            std::vector<uint8_t> td(type, type + 4);
+            td.insert(td.end(), body.begin(), body.end());
+            uint32_t crc = 0xFFFFFFFFu; // CRC-32 (IEEE 802.3) of type + data
+            for (uint8_t byte : td) {
+                crc ^= byte;
+                for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+            }
+            out.insert(out.end(), td.begin(), td.end());
+            be32(out, ~crc);
+        };
+        std::vector<uint8_t> ihdr;
+        be32(ihdr, width_); be32(ihdr, height_);
+        ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0}); // bit depth 8, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+        chunk("IHDR", ihdr);
+        chunk("IDAT", z);
+        chunk("IEND", {});
+        return out;
+    }
+    bool write_png(const std::string &path) const {
+        const std::vector<uint8_t> bytes = to_png();
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) return false;
+        const bool ok = std::fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+        return std::fclose(f) == 0 && ok;
     }
     // write_ppm (canvas.rs:69-93) with MaxWidthWriter's 70-column wrap (113-181): a line is broken at the
     // last space at or before column 70.

@@ -204,7 +204,7 @@ PYBIND11_MODULE(_front, m) {
     m.def("build_bounding_tree", [](const Group &g, size_t n) { return build_bounding_tree(g, n); });
 
     py::class_<ObjParser>(m, "ObjParser")
-        .def_static("parse_str", &ObjParser::parse_str)
+        .def_static("parse_str", &ObjParser::parse_str, py::arg("input"), py::arg("skip_texture_lines") = false)
         .def("ignored", &ObjParser::ignored).def("get_group", &ObjParser::get_group).def("into_group", &ObjParser::into_group)
         .def_readonly("vertices", &ObjParser::vertices).def_readonly("normals", &ObjParser::normals);
 
@@ -214,6 +214,8 @@ PYBIND11_MODULE(_front, m) {
         .def("set_pixel", &Canvas::set_pixel).def("add_to_pixel", &Canvas::add_to_pixel).def("get_pixel", &Canvas::get_pixel)
         .def("average_brightness", &Canvas::average_brightness)
         .def("to_ppm", &Canvas::to_ppm)
+        .def("to_png", [](const Canvas &c) { auto v = c.to_png(); return py::bytes(reinterpret_cast<const char *>(v.data()), v.size()); })
+        .def("write_png", &Canvas::write_png)
         .def("to_rgb8", [](const Canvas &c) {
             auto v = c.to_rgb8();
             py::array_t<uint8_t> a({(py::ssize_t)c.height(), (py::ssize_t)c.width(), (py::ssize_t)3});
