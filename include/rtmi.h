@@ -253,6 +253,20 @@ int rtmi_render_device_noalloc(const rtmi_scene *scene, const rtmi_camera *camer
                                const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
                                void *hip_stream);
 
+/* Replaces the refinement loop of `Camera::render_interactive` / `render_live` (camera.rs:163-248: pixels arrive while
+ * the frame is still being sampled) for a headless caller: the frame pass by pass.  Every pass takes each pixel from
+ * the sums the pass before left it with up to `max_samples` samples in all (0 = to the end of camera.rs:290-299) and
+ * hands back the whole frame, so early passes are previews and the later ones cost only the samples they add: the
+ * samples of all passes together are those of one rtmi_render call with the last cap, and the frame after a pass IS
+ * the frame rtmi_render gives with that cap, bit for bit.  The handle owns device memory for the frame and 32 bytes of
+ * state per pixel (56 in f64 mode); HOST buffer out; whole frame on the current device (opts->rank/nranks ignored).  */
+typedef struct rtmi_progressive rtmi_progressive;
+int rtmi_progressive_begin(const rtmi_scene *scene, const rtmi_camera *camera,
+                           const rtmi_render_opts *opts, rtmi_progressive **out);
+int rtmi_progressive_pass(rtmi_progressive *p, int32_t max_samples, float *rgb_out,
+                          rtmi_stats *stats_out);
+void rtmi_progressive_end(rtmi_progressive *p);
+
 /* Replaces `Color::to_u8` over a canvas (color.rs:53-60, canvas.rs:101-107): clip to [0,1],
  * x255, round half away from zero.  Device buffers, asynchronous.                               */
 int rtmi_tonemap_u8_device(const float *d_rgb, uint8_t *d_rgb8, int64_t n_values, void *hip_stream);

@@ -1035,13 +1035,29 @@ struct Camera {
         for (int c : caps)
             if (c > 0 && (final_cap <= 0 || c < final_cap) && (passes.empty() || c > passes.back())) passes.push_back(c);
         passes.push_back(final_cap);
+        // rtmi_progressive_*: the per-pixel sums stay on the device between the passes, so a pass costs only the samples
+        // it adds and the last one leaves exactly the frame Camera::render gives (stats: summed over the passes)
+        rtmi_camera c = abi();
+        rtmi_progressive *prog = nullptr;
+        if (rtmi_progressive_begin(scene.handle, &c, &o, &prog) != RTMI_OK) throw std::runtime_error(std::string("rtmi_progressive_begin: ") + rtmi_last_error());
         Canvas canvas(hsize_, vsize_);
+        std::vector<float> rgb((size_t)hsize_ * vsize_ * 3);
+        if (stats) std::memset(stats, 0, sizeof *stats);
         for (size_t k = 0; k < passes.size(); ++k) {
-            o.max_samples = passes[k];
-            const bool last = k + 1 == passes.size();
-            canvas = render(scene, &o, last ? stats : nullptr);
+            rtmi_stats st;
+            if (rtmi_progressive_pass(prog, passes[k], rgb.data(), &st) != RTMI_OK) {
+                const std::string msg = rtmi_last_error();
+                rtmi_progressive_end(prog);
+                throw std::runtime_error("rtmi_progressive_pass: " + msg);
+            }
+            if (stats) {
+                for (int i = 0; i < RTMI_N_STATS; ++i) stats->counter[i] += st.counter[i];
+                stats->kernel_ms += st.kernel_ms;
+            }
+            for (size_t i = 0; i < canvas.data.size(); ++i) canvas.data[i] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
             if (!pass_callback((int)k, (int)passes.size(), static_cast<const Canvas &>(canvas))) break;
         }
+        rtmi_progressive_end(prog);
         return canvas;
     }
 };

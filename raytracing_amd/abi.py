@@ -13,7 +13,7 @@ STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_
 
 # every symbol include/rtmi.h declares
 SYMBOLS = (
-    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc", "rtmi_render_device_timed",
+    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc", "rtmi_render_device_timed", "rtmi_progressive_begin", "rtmi_progressive_pass", "rtmi_progressive_end",
     "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
 )
 
@@ -57,6 +57,10 @@ def lib():
         L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtmi_render_device_noalloc.argtypes = L.rtmi_render_device.argtypes
         L.rtmi_render_device_timed.argtypes = L.rtmi_render_device.argtypes + [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rtmi_progressive_begin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.POINTER(C.c_void_p)]
+        L.rtmi_progressive_pass.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
+        L.rtmi_progressive_end.argtypes = [C.c_void_p]
+        L.rtmi_progressive_end.restype = None
         L.rtmi_tonemap_u8_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.rtmi_trace_rays.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
@@ -146,6 +150,36 @@ def render_device_timed(scene, camera, opts, out_tensor, stats_tensor=None, stre
     check(lib().rtmi_render_device_timed(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream, C.byref(a), C.byref(b)),
           "rtmi_render_device_timed")
     return float(a.value), float(b.value)
+
+
+class Progressive:
+    """rtmi_progressive_*: the frame pass by pass, each pass going on from the sums of the one before."""
+
+    def __init__(self, scene, camera, opts=None):
+        self._cam = camera.abi()
+        self.shape = (camera.vsize(), camera.hsize(), 3)
+        h = C.c_void_p()
+        opts = opts or make_opts()
+        check(lib().rtmi_progressive_begin(scene.handle, self._cam.address(), C.byref(opts), C.byref(h)), "rtmi_progressive_begin")
+        self.handle = h
+
+    def render_pass(self, max_samples):
+        import numpy as np
+        out = np.empty(self.shape, dtype=np.float32)
+        st = Stats()
+        check(lib().rtmi_progressive_pass(self.handle, max_samples, out.ctypes.data, C.byref(st)), "rtmi_progressive_pass")
+        return out, st.as_dict()
+
+    def close(self):
+        if self.handle:
+            lib().rtmi_progressive_end(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tonemap_u8_device(rgb_tensor, out_tensor, stream=0):

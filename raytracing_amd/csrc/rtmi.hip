@@ -961,7 +961,7 @@ static int check_camera(const rtmi_camera *c) {
 static long spread_below() { return env_long("RTMI_SPREAD_BELOW", (long)RTMI_SPREAD_BELOW); }
 
 static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_render_opts *o, float *d_out, uint64_t *d_stats, hipStream_t st,
-                         void *static_work = nullptr, size_t static_bytes = 0, hipEvent_t between = nullptr) {
+                         void *static_work = nullptr, size_t static_bytes = 0, hipEvent_t between = nullptr, void *state = nullptr) {
     int rank = 0, nranks = 1, tr = 8;
     if (o && o->nranks > 1) {
         nranks = o->nranks; rank = o->rank; tr = norm_tile_rows(o->tile_rows);
@@ -991,7 +991,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     const int first_samples = std::max(1, (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples);
     // (Both instantiations round every sample alike - Makefile, -ffp-contract=on - so the choice may look at this rank's
     // share of the frame without the image depending on the sharding: tests/test_gpu_first_pass_modes.py.)
-    const bool spread = first_samples > 1 && first_samples <= 64 && (long long)rp.n_tiles < (long long)s->num_cu * 12 * spread_below();
+    const bool spread = !state && first_samples > 1 && first_samples <= 64 && (long long)rp.n_tiles < (long long)s->num_cu * 12 * spread_below(); // (a progressive pass resumes pixels: one lane each)
     rp.first = (uint32_t)first_samples;
     rp.group = spread ? (uint32_t)first_samples : 1u;
     rp.ppw = 64u / rp.group;
@@ -1050,8 +1050,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
         HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st)); // (the array keeps the last call's contents: the counters must start at zero)
     }
     const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
-    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, wbytes, between);
-    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, wbytes, between);
+    if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, wbytes, between, state);
+    else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, wbytes, between, state);
     HIP_TRY(hipGetLastError());
     if (slot >= 0) { // the slot is this stream's until this point of the stream has been reached
         WorkPool &p = g_pool[s->device];
@@ -1096,6 +1096,77 @@ extern "C" int rtmi_render_device_timed(const rtmi_scene *scene, const rtmi_came
 #undef TRY_EV
     cleanup();
     return RTMI_OK;
+}
+
+// ---- progressive rendering: the frame pass by pass, every pass going on from the sums the pass before left ----
+struct rtmi_progressive {
+    const rtmi_scene *scene = nullptr;
+    rtmi_camera camera;
+    rtmi_render_opts opts;
+    float *d_out = nullptr;
+    void *d_state = nullptr;
+    uint64_t *d_stats = nullptr;
+    int passes = 0;
+};
+
+extern "C" void rtmi_progressive_end(rtmi_progressive *p) {
+    if (!p) return;
+    (void)hipFree(p->d_out); (void)hipFree(p->d_state); (void)hipFree(p->d_stats);
+    delete p;
+}
+
+extern "C" int rtmi_progressive_begin(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, rtmi_progressive **out) {
+    if (!out) return fail(RTMI_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!scene) return fail(RTMI_ERR_INVALID, "null scene");
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    rtmi_progressive *p = new rtmi_progressive();
+    p->scene = scene; p->camera = *camera;
+    memset(&p->opts, 0, sizeof p->opts);
+    if (opts) p->opts = *opts;
+    p->opts.rank = 0; p->opts.nranks = 1;
+    if (p->opts.precision != RTMI_PRECISION_F32 && p->opts.precision != RTMI_PRECISION_F64) { delete p; return fail(RTMI_ERR_INVALID, "bad precision"); }
+    const size_t pixels = (size_t)camera->hsize * camera->vsize;
+    const size_t state_bytes = pixels * (p->opts.precision == RTMI_PRECISION_F64 ? sizeof(DPixelState<double>) : sizeof(DPixelState<float>));
+    hipError_t e = hipMalloc((void **)&p->d_out, pixels * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&p->d_state, state_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_stats, RTMI_N_STATS * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(p->d_state, 0, state_bytes); // cnt = 0: nothing taken yet
+    if (e == hipSuccess) e = hipMemset(p->d_out, 0, pixels * 3 * sizeof(float));
+    if (e != hipSuccess) { rtmi_progressive_end(p); return fail(RTMI_ERR_NOMEM, std::string("rtmi_progressive_begin: ") + hipGetErrorString(e)); }
+    *out = p;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_progressive_pass(rtmi_progressive *p, int32_t max_samples, float *rgb_out, rtmi_stats *stats_out) {
+    if (!p || !rgb_out) return fail(RTMI_ERR_INVALID, "null progressive handle or output");
+    if (max_samples < 0) return fail(RTMI_ERR_INVALID, "negative sample cap");
+    rtmi_render_opts o = p->opts;
+    o.max_samples = max_samples;
+    HIP_TRY(hipMemset(p->d_stats, 0, RTMI_N_STATS * sizeof(uint64_t)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    hipError_t err = hipEventCreate(&e1);
+    if (err != hipSuccess) { (void)hipEventDestroy(e0); return fail(RTMI_ERR_DEVICE, hipGetErrorString(err)); }
+    (void)hipEventRecord(e0, 0);
+    int rc = launch_render(p->scene, &p->camera, &o, p->d_out, p->d_stats, 0, nullptr, 0, nullptr, p->d_state);
+    (void)hipEventRecord(e1, 0);
+    if (rc == RTMI_OK) {
+        err = hipEventSynchronize(e1);
+        if (err == hipSuccess) err = hipMemcpy(rgb_out, p->d_out, (size_t)p->camera.hsize * p->camera.vsize * 3 * sizeof(float), hipMemcpyDeviceToHost);
+        if (err == hipSuccess && stats_out) {
+            memset(stats_out, 0, sizeof *stats_out);
+            err = hipMemcpy(stats_out->counter, p->d_stats, RTMI_N_STATS * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            float ms = 0;
+            if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+            stats_out->kernel_ms = ms;
+        }
+        if (err != hipSuccess) rc = fail(RTMI_ERR_DEVICE, std::string("rtmi_progressive_pass: ") + hipGetErrorString(err));
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc == RTMI_OK) ++p->passes;
+    return rc;
 }
 
 extern "C" int rtmi_render_device_noalloc(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *d_rgb_out,

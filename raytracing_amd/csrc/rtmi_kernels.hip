@@ -173,6 +173,16 @@ __device__ __forceinline__ bool pop(uint32_t *__restrict__ hdr, int queue, uint3
     return false;
 }
 
+// a finished (for this pass) pixel's sums go back to the progressive state, if there is one
+template <typename R>
+__device__ __forceinline__ void keep_state(DPixelState<R> *__restrict__ state, size_t pixel, V3<R> sum, V3<R> sos, uint32_t cnt) {
+    if (!state) return;
+    DPixelState<R> &s = state[pixel];
+    s.sum[0] = sum.x; s.sum[1] = sum.y; s.sum[2] = sum.z;
+    s.sos[0] = sos.x; s.sos[1] = sos.y; s.sos[2] = sos.z;
+    s.cnt = cnt;
+}
+
 // Camera::render / trace_pixels / multisample (camera.rs:155-161,250-310), first pass: one wave64 per 8x8 pixel tile,
 // waves stride over the tiles this rank owns; every pixel takes its first min_samples samples on its own lane (all 64
 // lanes busy, neighbouring rays coherent).  Pixels the reference's loop would stop at (camera.rs:290-291) are written
@@ -183,7 +193,7 @@ template <typename R, bool TREE, bool SPREAD>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
-                                                    uint32_t wk_cap) {
+                                                    uint32_t wk_cap, DPixelState<R> *__restrict__ state) {
     // (the work pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
     // written in this kernel and fetch the wave-uniform ones with scalar loads)
     stage_scene<R, TREE>(sc);
@@ -218,7 +228,13 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
         const bool owner = valid && sidx == 0; // the lane that keeps the pixel's sums
         V3<R> sum = mk<R>(0, 0, 0), sos = mk<R>(0, 0, 0);
         uint32_t cnt = 0;
-        bool go = SPREAD ? true : valid, queued = false, full = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
+        if (!SPREAD && state && valid) { // a progressive pass goes on from where the pass before left the pixel (never SPREAD)
+            const DPixelState<R> &ps = state[(size_t)ly * cam.hsize + x];
+            sum = mk<R>(ps.sum[0], ps.sum[1], ps.sum[2]); sos = mk<R>(ps.sos[0], ps.sos[1], ps.sos[2]);
+            cnt = ps.cnt;
+        }
+        // (need_more is true at cnt == 0; a pixel that an earlier pass brought to its end takes nothing and is written again)
+        bool go = SPREAD ? true : (valid && need_more(cam, sum, sos, (R)cnt, cnt)), queued = false, full = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
         while (go) { // wave-uniform until the pixels' sums hold `first` samples
             V3<R> c = mk<R>(0, 0, 0);
             if (!SPREAD || valid) c = take_sample<R, TREE>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
@@ -276,6 +292,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
             R inv = (R)1 / (R)cnt;
             size_t o = ((size_t)ly * cam.hsize + x) * 3;
             out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
+            keep_state<R>(state, (size_t)ly * cam.hsize + x, sum, sos, cnt);
         }
     }
     flush_stats(st, stats);
@@ -321,7 +338,8 @@ __device__ __forceinline__ void seq_scan(V3<R> sum0, V3<R> sos0, V3<R> c, int G,
 template <typename R>
 __device__ __forceinline__ void sum_up_units(const DCamera<double> &cam, float *__restrict__ out, uint32_t *__restrict__ hdr,
                                              DWorkItem<R> *__restrict__ heavy, uint32_t *__restrict__ final_idx, uint32_t *__restrict__ unit_pixel,
-                                             const DChunk<R> *chunks, uint32_t unit_cap, uint32_t p, int pass, Stats &st, int lane) {
+                                             const DChunk<R> *chunks, uint32_t unit_cap, uint32_t p, int pass, Stats &st, int lane,
+                                             DPixelState<R> *__restrict__ state) {
     DWorkItem<R> *it = heavy + p;
     V3<R> sum = mk<R>(it->sum[0], it->sum[1], it->sum[2]), sos = mk<R>(it->sos[0], it->sos[1], it->sos[2]);
     uint32_t cnt = it->cnt;
@@ -375,6 +393,7 @@ __device__ __forceinline__ void sum_up_units(const DCamera<double> &cam, float *
         const R inv = (R)1 / (R)cnt;
         const size_t o = ((size_t)it->out_row * cam.hsize + it->px) * 3;
         out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
+        keep_state<R>(state, (size_t)it->out_row * cam.hsize + it->px, sum, sos, cnt);
     } else {
         it->cnt = cnt;
         it->sum[0] = sum.x; it->sum[1] = sum.y; it->sum[2] = sum.z;
@@ -389,7 +408,7 @@ template <typename R>
 __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *__restrict__ out, unsigned long long *__restrict__ stats,
                                                     uint32_t *__restrict__ wk_hdr, DWorkItem<R> *__restrict__ wk_heavy, uint32_t *__restrict__ wk_final,
                                                     uint32_t *__restrict__ wk_unit_pixel, const DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap,
-                                                    uint32_t wk_unit_cap, int pass) {
+                                                    uint32_t wk_unit_cap, int pass, DPixelState<R> *__restrict__ state) {
     Stats st;
     stats_zero(st);
     const int lane = threadIdx.x & 63;
@@ -403,7 +422,7 @@ __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *
         while (firsts) {
             const int i = __ffsll((long long)firsts) - 1;
             firsts &= firsts - 1ull;
-            sum_up_units<R>(cam, out, wk_hdr, wk_heavy, wk_final, wk_unit_pixel, wk_chunks, wk_unit_cap, __shfl(p, i, 64), pass, st, lane);
+            sum_up_units<R>(cam, out, wk_hdr, wk_heavy, wk_final, wk_unit_pixel, wk_chunks, wk_unit_cap, __shfl(p, i, 64), pass, st, lane, state);
         }
     }
     flush_stats(st, stats, true);
@@ -431,7 +450,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                       const DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
                                                       uint32_t *__restrict__ wk_final, uint32_t *__restrict__ wk_unit_pixel, uint32_t wk_cap,
-                                                      uint32_t wk_unit_cap, int pass) {
+                                                      uint32_t wk_unit_cap, int pass, DPixelState<R> *__restrict__ state) {
     Stats st;
     stats_zero(st);
     Rng rng;
@@ -552,6 +571,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
             R inv = (R)1 / (R)cnt;
             size_t o = ((size_t)out_row * cam.hsize + px) * 3;
             out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
+            keep_state<R>(state, (size_t)out_row * cam.hsize + px, sum, sos, cnt);
         }
     }
     flush_stats(st, stats, true);
@@ -678,13 +698,14 @@ namespace rtmi_dev {
 template <>
 void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hipStream_t st, const DScene<RTMI_REAL> &sc,
                                      const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
-                                     size_t work_bytes, hipEvent_t between) {
+                                     size_t work_bytes, hipEvent_t between, void *state_) {
     DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
+    DPixelState<RTMI_REAL> *state = (DPixelState<RTMI_REAL> *)state_;
     const bool spread = rp.group > 1;
-    if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
-    else if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
-    else if (spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
-    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap);
+    if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
+    else if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
+    else if (spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
+    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
     if (between) (void)hipEventRecord(between, st); // (rtmi_render_device_timed)
     if (!wk.hdr || grid_resample <= 0) return;
     for (int l = 0; l <= RTMI_SPEC_PASSES + 1; ++l) {
@@ -693,17 +714,17 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
         if (pass > 0) {
             if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
             else hipLaunchKernelGGL((units_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
-            hipLaunchKernelGGL(sum_up_kernel<RTMI_REAL>, dim3(grid_resample), dim3(64), 0, st, cam, out, stats, wk.hdr, wk.heavy, wk.final_idx, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            hipLaunchKernelGGL(sum_up_kernel<RTMI_REAL>, dim3(grid_resample), dim3(64), 0, st, cam, out, stats, wk.hdr, wk.heavy, wk.final_idx, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, state);
         } else {
-            if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass);
-            else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass);
+            if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
+            else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
         }
     }
 }
 #else
 template <>
 void launch_render_kernel<RTMI_REAL>(bool, int, int, hipStream_t, const DScene<RTMI_REAL> &, const DCamera<double> &, const DRender &, float *,
-                                     unsigned long long *, void *, size_t, hipEvent_t) {}
+                                     unsigned long long *, void *, size_t, hipEvent_t, void *) {}
 #endif
 template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,

@@ -66,6 +66,12 @@ template <typename R> struct DChunk {
     R col[3][64];
     uint32_t st[CHUNK_STAT_WORDS][64]; // primary | samples << 8 | overflow << 16, reflection, refraction, shadow, leaf tests, node visits, slab tests, flops
 };
+// What a pixel's sampling has come to, kept between the passes of a progressive render (rtmi_progressive_*): the next
+// pass goes on from these sums exactly where Camera::multisample's loop (camera.rs:281-299) would.
+template <typename R> struct DPixelState {
+    R sum[3], sos[3];
+    uint32_t cnt, pad;
+};
 template <typename R> struct DWork {
     uint32_t *hdr;
     DWorkItem<R> *light, *heavy;
@@ -97,15 +103,15 @@ template <typename R> inline DWork<R> make_work(void *work, size_t bytes) {
 
 template <typename R>
 void launch_render_kernel(bool tree, int grid, int grid_resample, hipStream_t st, const DScene<R> &sc, const DCamera<double> &cam,
-                          const DRender &rp, float *out, unsigned long long *stats, void *work, size_t work_bytes, hipEvent_t between);
+                          const DRender &rp, float *out, unsigned long long *stats, void *work, size_t work_bytes, hipEvent_t between, void *state);
 template <typename R>
 void launch_trace_kernel(int grid, const DScene<R> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
                          const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs);
 template <typename R>
 void launch_camera_rays_kernel(int grid, const DCamera<double> &cam, uint32_t seed_lo, uint32_t seed_hi, long long n, const int *px,
                                const int *py, const int *sample, double *origins, double *dirs);
-template <> void launch_render_kernel<float>(bool, int, int, hipStream_t, const DScene<float> &, const DCamera<double> &, const DRender &, float *, unsigned long long *, void *, size_t, hipEvent_t);
-template <> void launch_render_kernel<double>(bool, int, int, hipStream_t, const DScene<double> &, const DCamera<double> &, const DRender &, float *, unsigned long long *, void *, size_t, hipEvent_t);
+template <> void launch_render_kernel<float>(bool, int, int, hipStream_t, const DScene<float> &, const DCamera<double> &, const DRender &, float *, unsigned long long *, void *, size_t, hipEvent_t, void *);
+template <> void launch_render_kernel<double>(bool, int, int, hipStream_t, const DScene<double> &, const DCamera<double> &, const DRender &, float *, unsigned long long *, void *, size_t, hipEvent_t, void *);
 template <> void launch_trace_kernel<float>(int, const DScene<float> &, uint32_t, uint32_t, long long, const double *, const double *, const int *, double *, rtmi_hit_record *);
 template <> void launch_trace_kernel<double>(int, const DScene<double> &, uint32_t, uint32_t, long long, const double *, const double *, const int *, double *, rtmi_hit_record *);
 template <> void launch_camera_rays_kernel<float>(int, const DCamera<double> &, uint32_t, uint32_t, long long, const int *, const int *, const int *, double *, double *);
