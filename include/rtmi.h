@@ -230,6 +230,19 @@ int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera,
                        const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
                        void *hip_stream);
 
+/* `Camera::render` on several GPUs of ONE process (the reference's only fan-out is rayon's, camera.rs:260-264; the
+ * one-process-per-GPU form of this is rtmi_render_device with opts->rank/nranks plus an RCCL gather, bench.py).
+ * scenes[r] is the same world created on the device that renders share r (rtmi_scene_create with that device
+ * current; several or all may live on one device).  Share r = the row tiles t with t % n_scenes == r, tile_rows rows
+ * each (0 = 8).  All shares are enqueued before any is waited for; the rows are then gathered to scenes[0]'s device -
+ * peer copies over xGMI for shares rendered elsewhere - and put in place there by a small kernel.  d_rgb_out: the
+ * WHOLE frame, vsize*hsize*3 floats in memory of scenes[0]'s device.  The image is the single-GPU image bit for bit
+ * (RNG keyed by global pixel and sample).  Blocking; allocates and frees its staging buffers; stats_out (may be NULL)
+ * = counters summed over the shares, kernel_ms = the call on scenes[0]'s device.                                */
+int rtmi_render_multi(const rtmi_scene *const *scenes, int32_t n_scenes, const rtmi_camera *camera,
+                      const rtmi_render_opts *opts, int32_t tile_rows, float *d_rgb_out,
+                      rtmi_stats *stats_out);
+
 /* Diagnostic twin of rtmi_render_device for measurement (bench.py's roofline figures): the same launches with HIP
  * events recorded on `hip_stream` before the first pass (render_kernel), between it and the second pass
  * (resample / units / sum_up kernels) and after it; waits for the call to finish and returns the two durations in

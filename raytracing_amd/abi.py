@@ -13,7 +13,7 @@ STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_
 
 # every symbol include/rtmi.h declares
 SYMBOLS = (
-    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc", "rtmi_render_device_timed", "rtmi_progressive_begin", "rtmi_progressive_pass", "rtmi_progressive_end",
+    "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc", "rtmi_render_device_timed", "rtmi_render_multi", "rtmi_progressive_begin", "rtmi_progressive_pass", "rtmi_progressive_end",
     "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
 )
 
@@ -57,6 +57,7 @@ def lib():
         L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtmi_render_device_noalloc.argtypes = L.rtmi_render_device.argtypes
         L.rtmi_render_device_timed.argtypes = L.rtmi_render_device.argtypes + [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rtmi_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(RenderOpts), C.c_int32, C.c_void_p, C.POINTER(Stats)]
         L.rtmi_progressive_begin.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RenderOpts), C.POINTER(C.c_void_p)]
         L.rtmi_progressive_pass.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
         L.rtmi_progressive_end.argtypes = [C.c_void_p]
@@ -150,6 +151,16 @@ def render_device_timed(scene, camera, opts, out_tensor, stats_tensor=None, stre
     check(lib().rtmi_render_device_timed(scene.handle, cam.address(), C.byref(opts), out_tensor.data_ptr(), sp, stream, C.byref(a), C.byref(b)),
           "rtmi_render_device_timed")
     return float(a.value), float(b.value)
+
+
+def render_multi(scene_list, camera, opts, out_tensor, tile_rows=8):
+    """rtmi_render_multi: share r of the frame on scene_list[r]'s device, rows gathered into out_tensor (whole frame, on
+    scene_list[0]'s device).  Returns the summed stats."""
+    cam = camera.abi()
+    arr = (C.c_void_p * len(scene_list))(*[s.handle for s in scene_list])
+    st = Stats()
+    check(lib().rtmi_render_multi(arr, len(scene_list), cam.address(), C.byref(opts), tile_rows, out_tensor.data_ptr(), C.byref(st)), "rtmi_render_multi")
+    return st.as_dict()
 
 
 class Progressive:

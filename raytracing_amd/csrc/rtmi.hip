@@ -56,6 +56,16 @@ __global__ void tonemap_kernel(const float *__restrict__ in, uint8_t *__restrict
     }
 }
 
+// rank r's compact rows (tile t of the rank = tile t * nranks + r of the frame) to their places in the whole frame
+__global__ void deinterleave_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n_values, int row_values, int tile_rows, int rank,
+                                    int nranks) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / row_values, col = i - row * row_values;
+        const long long tile = row / tile_rows, within = row - tile * tile_rows;
+        dst[((tile * nranks + rank) * tile_rows + within) * row_values + col] = src[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host: scene layout
 // ---------------------------------------------------------------------------------------------
@@ -1094,6 +1104,95 @@ extern "C" int rtmi_render_device_timed(const rtmi_scene *scene, const rtmi_came
         TRY_EV(hipEventElapsedTime(ms_second_pass, ev[1], ev[2]));
     }
 #undef TRY_EV
+    cleanup();
+    return RTMI_OK;
+}
+
+// ---- one process, several GPUs: row tiles rendered where the scenes live, rows gathered to the first scene's device ----
+extern "C" int rtmi_render_multi(const rtmi_scene *const *scenes, int32_t n_scenes, const rtmi_camera *camera, const rtmi_render_opts *opts,
+                                 int32_t tile_rows, float *d_rgb_out, rtmi_stats *stats_out) {
+    if (!scenes || n_scenes <= 0 || !d_rgb_out) return fail(RTMI_ERR_INVALID, "null scenes or output");
+    for (int r = 0; r < n_scenes; ++r)
+        if (!scenes[r]) return fail(RTMI_ERR_INVALID, "null scene " + std::to_string(r));
+    int rc = check_camera(camera);
+    if (rc != RTMI_OK) return rc;
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    const int N = n_scenes, tr = norm_tile_rows(tile_rows), dev0 = scenes[0]->device;
+    const size_t row_values = (size_t)camera->hsize * 3;
+    std::vector<float *> rows((size_t)N, nullptr);   // each rank's compact rows, on its device
+    std::vector<uint64_t *> dstats((size_t)N, nullptr);
+    float *stage = nullptr;                           // on the first device: a remote rank's rows before they are put in place
+    size_t stage_values = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        for (int r = 0; r < N; ++r) {
+            if (rows[(size_t)r] || dstats[(size_t)r]) { (void)hipSetDevice(scenes[r]->device); (void)hipFree(rows[(size_t)r]); (void)hipFree(dstats[(size_t)r]); }
+        }
+        (void)hipSetDevice(dev0);
+        (void)hipFree(stage);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipSetDevice(prev);
+    };
+#define TRY_MULTI(expr)                                                                                            \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess) { cleanup(); return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    rtmi_render_opts o;
+    memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    o.nranks = N; o.tile_rows = tr;
+    TRY_MULTI(hipSetDevice(dev0));
+    TRY_MULTI(hipEventCreate(&e0));
+    TRY_MULTI(hipEventCreate(&e1));
+    TRY_MULTI(hipEventRecord(e0, 0));
+    // every rank's kernels are enqueued before any is waited for: the devices render at the same time
+    for (int r = 0; r < N; ++r) {
+        const size_t values = (size_t)rtmi_rank_rows(camera->vsize, r, N, tr) * row_values;
+        TRY_MULTI(hipSetDevice(scenes[r]->device));
+        TRY_MULTI(hipMalloc((void **)&dstats[(size_t)r], RTMI_N_STATS * sizeof(uint64_t)));
+        TRY_MULTI(hipMemsetAsync(dstats[(size_t)r], 0, RTMI_N_STATS * sizeof(uint64_t), 0));
+        if (values == 0) continue;
+        TRY_MULTI(hipMalloc((void **)&rows[(size_t)r], values * sizeof(float)));
+        o.rank = r;
+        rc = launch_render(scenes[r], camera, &o, rows[(size_t)r], dstats[(size_t)r], 0);
+        if (rc != RTMI_OK) { cleanup(); return rc; }
+        if (scenes[r]->device != dev0) stage_values = std::max(stage_values, values);
+    }
+    TRY_MULTI(hipSetDevice(dev0));
+    if (stage_values) TRY_MULTI(hipMalloc((void **)&stage, stage_values * sizeof(float)));
+    rtmi_stats total;
+    memset(&total, 0, sizeof total);
+    for (int r = 0; r < N; ++r) {
+        const size_t values = (size_t)rtmi_rank_rows(camera->vsize, r, N, tr) * row_values;
+        const int dev = scenes[r]->device;
+        TRY_MULTI(hipSetDevice(dev));
+        TRY_MULTI(hipDeviceSynchronize()); // this rank's rows are complete
+        uint64_t c[RTMI_N_STATS];
+        TRY_MULTI(hipMemcpy(c, dstats[(size_t)r], sizeof c, hipMemcpyDeviceToHost));
+        for (int k = 0; k < RTMI_N_STATS; ++k) total.counter[k] += c[k];
+        if (values == 0) continue;
+        TRY_MULTI(hipSetDevice(dev0));
+        const float *src = rows[(size_t)r];
+        if (dev != dev0) { // over xGMI into the staging buffer (the copy engine; no kernel reads remote memory)
+            TRY_MULTI(hipMemcpyPeer(stage, dev0, rows[(size_t)r], dev, values * sizeof(float)));
+            src = stage;
+        }
+        const int grid = (int)std::min<size_t>((values + 255) / 256, 65535);
+        hipLaunchKernelGGL(deinterleave_kernel, dim3(grid), dim3(256), 0, 0, src, d_rgb_out, (long long)values, (int)row_values, tr, r, N);
+        TRY_MULTI(hipGetLastError());
+        if (dev != dev0) TRY_MULTI(hipDeviceSynchronize()); // (the staging buffer is reused by the next remote rank)
+    }
+    TRY_MULTI(hipSetDevice(dev0));
+    TRY_MULTI(hipEventRecord(e1, 0));
+    TRY_MULTI(hipEventSynchronize(e1));
+    float ms = 0;
+    TRY_MULTI(hipEventElapsedTime(&ms, e0, e1));
+    total.kernel_ms = ms;
+    if (stats_out) *stats_out = total;
+#undef TRY_MULTI
     cleanup();
     return RTMI_OK;
 }

@@ -39,6 +39,7 @@ inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return
 template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyPeer(void *d, int, const void *s, int, size_t n) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 template <typename T> inline hipError_t hipGetSymbolAddress(void **p, const T &symbol) { *p = (void *)&symbol; return hipSuccess; } // a "device" array is a host array here
