@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device)")
     ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice")
     ap.add_argument("--width", type=int, default=3840)

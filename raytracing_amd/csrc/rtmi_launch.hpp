@@ -37,7 +37,7 @@ static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
 #define RTMI_LIGHT_NEED 128 // predicted further samples up to which a pixel goes to the light queue
 #endif
 #ifndef RTMI_LIGHT_BATCH
-#define RTMI_LIGHT_BATCH 2  // light pixels per wave (a power of two): 32 lanes per pixel
+#define RTMI_LIGHT_BATCH 4  // light pixels per wave (a power of two): 16 lanes per pixel (round 2, with most pixels past min_samples: 4 beats 2 by 2 - 3 %)
 #endif
 #ifndef RTMI_LIGHT_POP
 #define RTMI_LIGHT_POP 1 // most light batches a wave pops at once (neighbours in the queue are neighbours in the image and cost
