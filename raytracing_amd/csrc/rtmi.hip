@@ -209,6 +209,8 @@ struct rtmi_scene {
     DeviceArrays<double> f64;
     DNode *nodes = nullptr;
     DCsg *csgs = nullptr;
+    DGuard *csg_guard = nullptr;
+    DChain *csg_chain = nullptr;
     uint32_t *leaf_orig = nullptr;
     DWTri *wtris = nullptr;
     DBvh2 *bvh2 = nullptr;  // the device's own triangle BVHs (NODE_TRIBVH) and their triangles in leaf order
@@ -230,6 +232,7 @@ struct Layout {
     std::vector<uint8_t> leaf_shadow;  // device leaf -> casts shadows
     std::vector<DNode> nodes;
     std::vector<DCsg> csgs;
+    std::vector<uint32_t> csg_l0, csg_l2; // first leaf / one past the last leaf of every CSG operator
     std::string err;
     int err_code = RTMI_OK;
     std::vector<uint8_t> seen_leaf, seen_node;
@@ -285,9 +288,48 @@ struct Layout {
         DCsg c;
         c.op = (uint32_t)nd.kind; c.left_end = 0; c.parent = parent; c.bit = bit_counter++;
         csgs.push_back(c);
+        csg_l0.push_back((uint32_t)leaf_orig.size());
+        csg_l2.push_back(0);
         csg_side(nd.first, me, shadow, bit_counter);
         csgs[me].left_end = (uint32_t)leaf_orig.size();
         csg_side(nd.count, me, shadow, bit_counter);
+        csg_l2[me] = (uint32_t)leaf_orig.size();
+    }
+
+    // DGuard records (rtmi_device.hpp): one at the last leaf of the left side of every operator that is not a Union and has
+    // leaves on both sides; an operator that is the WHOLE left side of such an operator passes the jump on to its end.
+    // DChain records (rtmi_device.hpp): what CsgOp::eval (csg.rs:26-32) asks of the flags of every ancestor of a leaf
+    std::vector<DChain> chains() const {
+        std::vector<DChain> out(leaf_orig.size(), DChain{0ull, 0ull});
+        for (size_t li = 0; li < leaf_orig.size(); ++li) {
+            for (uint32_t c = leaf_csg[li]; c != NONE; c = csgs[c].parent) {
+                const DCsg &cn = csgs[c];
+                const bool lhit = li < cn.left_end;
+                const unsigned long long bit = 1ull << (2 * cn.bit + (lhit ? 1 : 0)); // a left root looks at inr, a right one at inl
+                bool want_set;
+                if (cn.op == (uint32_t)RTMI_NODE_CSG_UNION) want_set = false;              // (lhit && !inr) || (!lhit && !inl)
+                else if (cn.op == (uint32_t)RTMI_NODE_CSG_INTERSECTION) want_set = true;   // (lhit && inr) || (!lhit && inl)
+                else want_set = !lhit;                                                     // (lhit && !inr) || (!lhit && inl)
+                (want_set ? out[li].one : out[li].zero) |= bit;
+            }
+        }
+        return out;
+    }
+
+    std::vector<DGuard> guards() const {
+        std::vector<DGuard> g(leaf_orig.size(), DGuard{0u, 0u});
+        for (size_t me = 0; me < csgs.size(); ++me) {
+            const DCsg &c = csgs[me];
+            if (c.op == (uint32_t)RTMI_NODE_CSG_UNION || c.left_end <= csg_l0[me] || csg_l2[me] <= c.left_end) continue;
+            size_t top = me;
+            while (csgs[top].parent != NONE) {
+                size_t p = csgs[top].parent;
+                if (csgs[p].op == (uint32_t)RTMI_NODE_CSG_UNION || csg_l0[p] != csg_l0[top] || csgs[p].left_end != csg_l2[top]) break;
+                top = p;
+            }
+            g[c.left_end - 1] = DGuard{csg_l0[me], csg_l2[top]};
+        }
+        return g;
     }
 
     // fill device node `slot` from desc node n (a GROUP/BOUNDED or a CSG root)
@@ -791,7 +833,7 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
 
 template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_desc *d, const Layout &L, const DeviceArrays<R> &A, DScene<R> &h) {
     h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
-    h.nodes = s->nodes; h.csgs = s->csgs; h.leaf_orig = s->leaf_orig;
+    h.nodes = s->nodes; h.csgs = s->csgs; h.csg_guard = s->csg_guard; h.csg_chain = s->csg_chain; h.leaf_orig = s->leaf_orig;
     h.wtris = sizeof(R) == 4 ? s->wtris : nullptr;
     h.bvh2 = sizeof(R) == 4 ? s->bvh2 : nullptr;
     h.n_bvh2 = sizeof(R) == 4 ? s->n_bvh2 : 0u; h.n_btris = sizeof(R) == 4 ? s->n_btris : 0u;
@@ -848,7 +890,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -892,6 +934,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->bvh2, bvh2);
     if (rc == RTMI_OK) rc = upload(&s->btris, btris);
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
+    if (rc == RTMI_OK) rc = upload(&s->csg_guard, L.guards());
+    if (rc == RTMI_OK) rc = upload(&s->csg_chain, L.chains());
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
     std::vector<uint32_t> quick;
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &quick);

@@ -148,6 +148,19 @@ struct DCsg { // 16 B
     uint32_t bit;      // index of this operator under its root (state bits 2*bit, 2*bit+1)
 };
 
+// What the ray's misses so far say about a CSG root's remaining leaves (the device's own shortcut; it changes no result).
+// CsgOp::eval (csg.rs:26-32) lets a root of the RIGHT side of an Intersection or Difference through only while the ray is
+// inside the left side, and one of the LEFT side of an Intersection only while inside the right: an operator other than
+// Union whose left side gave the ray no root at all gives none itself, whatever its right side holds.  The record sits at
+// the LAST leaf of such an operator's left side: if no leaf from `start` (the operator's first leaf) up to here had a root,
+// go on at leaf `skip` - the end of the operator, or of the outermost enclosing operator it is the whole left side of and
+// that is no Union either.  A die of chapter-16 is ((((((cube & sphere) - side) - side) ...): a ray that misses the cube
+// is done with the die after one test instead of 23.
+struct DGuard { uint32_t start, skip; }; // skip == 0: no record at this leaf
+// A leaf's CSG ancestors as two masks over the root's operator flags (bit 2b = inl, 2b + 1 = inr of operator b): the flags
+// CsgOp::eval (csg.rs:26-32) needs clear / set for a root of this leaf to pass (see csg_root).
+struct alignas(16) DChain { unsigned long long zero, one; };
+
 template <typename R> struct DScene {
     const DLeaf<R> *leaves;
     const DTri<R> *tris;
@@ -156,6 +169,8 @@ template <typename R> struct DScene {
     const DLight<R> *lights;
     const DNode *nodes;
     const DCsg *csgs;
+    const DGuard *csg_guard;   // one per leaf
+    const DChain *csg_chain;   // one per leaf
     const uint32_t *leaf_orig; // device leaf -> index in rtmi_scene_desc.leaves
     const DWTri *wtris;        // one per entry of tris (f32 scene only, else null)
     const DBvh2 *bvh2;         // the NODE_TRIBVH trees (f32 scene only)
@@ -333,7 +348,19 @@ template <typename R> __device__ __forceinline__ R rng_next(Rng &g) {
 struct Stats {
     uint32_t c[RTMI_N_STATS]; // c[RTMI_STAT_FLOPS] is unused: flops are summed in 64 bits below
     unsigned long long flops;
+#ifdef RTMI_CYCLES
+    unsigned long long cyc[4]; // shader-clock cycles: 0 the tree walk (packet_scene), 1 csg_root's leaf loop, 2 its sort + filter, 3 the whole kernel
+#endif
 };
+// -DRTMI_CYCLES (a diagnostic build, tools/cycles.sh): where a wave's time goes, summed per wave into the counters
+// aabb_tests, leaf_tests, node_visits and flops INSTEAD of what those normally count.
+#ifdef RTMI_CYCLES
+#define CYC_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CYC_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
+#else
+#define CYC_BEGIN(v)
+#define CYC_END(st, i, v)
+#endif
 
 // Algorithmic FLOP prices per event (mul/add/sub/div/sqrt/exp2/log2 = 1, FMA = 2, compares = 0),
 // derived from the cited reference lines.  They price the REFERENCE's arithmetic, not this kernel's.
@@ -636,75 +663,142 @@ template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op
     if (leaf != hit_leaf && (op.other == NONE || t_entry > op.other_t)) { op.other = leaf; op.other_t = t_entry; }
 }
 
+// The intersections csg_root buffers, per lane: scratch memory.  -DRTMI_CSG_LDS=n keeps the first n of them in LDS
+// ([entry][lane]) instead; measured on the dice frame (a ray that hits a die has 4 to 8): n = 0 333 ms, 4 345 ms, 8 380 ms -
+// the per-lane scratch lines stay in the vector cache, and LDS is what the pending-ray stacks need.
+#ifndef RTMI_CSG_LDS
+#define RTMI_CSG_LDS 0
+#endif
+constexpr int CSG_LDS = RTMI_CSG_LDS;
+template <typename R> struct CsgBuf {
+    static constexpr int IN_LDS = sizeof(R) == 4 ? CSG_LDS : 0;
+    R deep_t[CSG_BUF - IN_LDS];
+    uint32_t deep_id[CSG_BUF - IN_LDS];
+    uint32_t (*lds)[CSG_LDS > 0 ? CSG_LDS : 1][64];
+    int lane;
+    __device__ __forceinline__ CsgBuf() {
+        if constexpr (IN_LDS > 0) {
+            __shared__ uint32_t s_csg[2][CSG_LDS > 0 ? CSG_LDS : 1][64]; // t bits, id
+            lds = s_csg;
+        } else lds = nullptr;
+#ifdef RTMI_HOST_EMUL
+        lane = 0;
+#else
+        lane = threadIdx.x & 63;
+#endif
+    }
+    __device__ __forceinline__ void put(int i, R t, uint32_t id) {
+        if constexpr (IN_LDS > 0) {
+            if (i < CSG_LDS) { lds[0][i][lane] = __builtin_bit_cast(uint32_t, t); lds[1][i][lane] = id; return; }
+        }
+        deep_t[i - IN_LDS] = t; deep_id[i - IN_LDS] = id;
+    }
+    __device__ __forceinline__ R t(int i) const {
+        if constexpr (IN_LDS > 0) {
+            if (i < CSG_LDS) return __builtin_bit_cast(R, lds[0][i][lane]);
+        }
+        return deep_t[i - IN_LDS];
+    }
+    __device__ __forceinline__ uint32_t id(int i) const {
+        if constexpr (IN_LDS > 0) {
+            if (i < CSG_LDS) return lds[1][i][lane];
+        }
+        return deep_id[i - IN_LDS];
+    }
+    __device__ __forceinline__ void set_id(int i, uint32_t id) {
+        if constexpr (IN_LDS > 0) {
+            if (i < CSG_LDS) { lds[1][i][lane] = id; return; }
+        }
+        deep_id[i - IN_LDS] = id;
+    }
+};
+
 // Evaluate one CSG root (CsgPair::intersect + filter_intersections, csg.rs:97-124, recursively):
 // buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
 // its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
 template <typename R, int MODE>
 __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
                          Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
-    R bt[CSG_BUF];
-    uint32_t bid[CSG_BUF];
+    CsgBuf<R> buf;
     int k = 0;
-    for (uint32_t li = leaf_first; li < leaf_first + leaf_count; ++li) {
+    CYC_BEGIN(c_leaf);
+    const uint32_t leaf_end = leaf_first + leaf_count;
+    uint32_t skip_until = leaf_first, last_root = NONE; // leaves below skip_until are not tested (DGuard); the last leaf that had a root
+    for (uint32_t li = leaf_first; li < leaf_end; ++li) {
         const DLeaf<R> &g = sc.leaves[li];
-        if (MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW)) continue;
-        R t[4], u, v;
-        int n = leaf_roots(g, g.kind, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
+        if (li >= skip_until && !(MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW))) {
+            R t[4], u, v;
+            int n = leaf_roots(g, g.kind, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
+            if (n > 0) last_root = li;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < n) {
-                if (k < CSG_BUF) { bt[k] = t[i]; bid[k] = li | ((uint32_t)i << ID_ORD_SHIFT); ++k; }
-                else st.c[RTMI_STAT_OVERFLOW] = 1;
+            for (int i = 0; i < 4; ++i) {
+                if (i < n) {
+                    if (k < CSG_BUF) { buf.put(k, t[i], li | ((uint32_t)i << ID_ORD_SHIFT)); ++k; }
+                    else st.c[RTMI_STAT_OVERFLOW] = 1;
+                }
             }
         }
+        const DGuard gd = sc.csg_guard[li];
+        if (gd.skip != 0 && li + 1 >= skip_until && (last_root == NONE || last_root < gd.start)) skip_until = max(skip_until, gd.skip);
+        if (__ballot(skip_until < leaf_end) == 0) break; // every lane that is here is done with this root
     }
+    CYC_END(st, 1, c_leaf);
+    CYC_BEGIN(c_sort);
+    // filter_intersections (csg.rs:107-124) for a root of leaf li, all its CSG ancestors at once.  CsgOp::eval depends, for
+    // a given operator and side, on ONE of the operator's two flags (a left root on inr, a right root on inl), so "passes
+    // every ancestor" is: the flags in chain.zero are clear and those in chain.one are set (DChain, built on the host).
+    // Every ancestor the root reaches toggles its other flag; it reaches them bottom-up until the first that stops it, and
+    // an ancestor's flags sit below its descendants' (operators are numbered parent first), so that is the HIGHEST
+    // failing flag and the toggles are those at or above its pair.
     unsigned long long state = 0; // bit 2b = inl, 2b+1 = inr of CSG operator b under this root
     for (int step = 0; step < k; ++step) {
         int m = -1;
         R mt = Lim<R>::inf();
-        for (int i = 0; i < k; ++i)
-            if (!(bid[i] & ID_DONE) && (m < 0 || bt[i] < mt)) { m = i; mt = bt[i]; }
-        uint32_t id = bid[m];
-        uint32_t li = id & ID_LEAF_MASK;
-        bool keep = true;
-        for (uint32_t c = sc.leaves[li].csg_parent; c != NONE;) {
-            DCsg cn = sc.csgs[c];
-            bool lhit = li < cn.left_end;
-            bool inl = (state >> (2 * cn.bit)) & 1ull, inr = (state >> (2 * cn.bit + 1)) & 1ull;
-            bool filt = csg_eval(cn.op, lhit, inl, inr);
-            state ^= 1ull << (2 * cn.bit + (lhit ? 0 : 1));
-            if (!filt) { keep = false; break; }
-            c = cn.parent;
+        uint32_t id = 0;
+        for (int i = 0; i < k; ++i) {
+            const uint32_t di = buf.id(i);
+            const R ti = buf.t(i);
+            if (!(di & ID_DONE) && (m < 0 || ti < mt)) { m = i; mt = ti; id = di; }
         }
-        bid[m] = id | ID_DONE | (keep ? ID_KEEP : 0u);
+        const uint32_t li = id & ID_LEAF_MASK;
+        const DChain ch = sc.csg_chain[li];
+        const unsigned long long tested = ch.zero | ch.one;
+        const unsigned long long fail = (state & ch.zero) | (~state & ch.one);
+        unsigned long long toggle = ((tested & 0x5555555555555555ull) << 1) | ((tested & 0xAAAAAAAAAAAAAAAAull) >> 1);
+        const bool keep = fail == 0ull;
+        if (!keep) toggle &= ~((1ull << ((63 - __clzll((long long)fail)) & ~1)) - 1ull);
+        state ^= toggle;
+        buf.set_id(m, id | ID_DONE | (keep ? ID_KEEP : 0u));
         if (MODE == MODE_COLLECT) continue;
         if (keep && mt >= (R)0) {
             if (mt < t_limit && mt < best.t) { best.t = mt; best.leaf = li; best.ord = (id >> ID_ORD_SHIFT) & 3u; }
-            return; // sorted: nothing later can be closer
+            break; // sorted: nothing later can be closer
         }
     }
+    CYC_END(st, 2, c_sort);
     if (MODE == MODE_COLLECT) {
         // survivors in front of the hit, per leaf: odd count = still open, entered at its last such root
         for (int i = 0; i < k; ++i) {
-            uint32_t id = bid[i];
+            uint32_t id = buf.id(i);
             if (!(id & ID_KEEP)) continue;
             uint32_t li = id & ID_LEAF_MASK, ord = (id >> ID_ORD_SHIFT) & 3u;
-            bool front = (li == hit_leaf) ? (ord < hit_ord) : (bt[i] < t_limit);
+            const R ti = buf.t(i);
+            bool front = (li == hit_leaf) ? (ord < hit_ord) : (ti < t_limit);
             if (!front) continue;
             int cnt = 0;
             bool last = true;
             for (int j = 0; j < k; ++j) {
-                uint32_t jd = bid[j];
+                uint32_t jd = buf.id(j);
                 if (!(jd & ID_KEEP) || (jd & ID_LEAF_MASK) != li) continue;
                 uint32_t jo = (jd >> ID_ORD_SHIFT) & 3u;
-                bool jfront = (li == hit_leaf) ? (jo < hit_ord) : (bt[j] < t_limit);
+                bool jfront = (li == hit_leaf) ? (jo < hit_ord) : (buf.t(j) < t_limit);
                 if (!jfront) continue;
                 ++cnt;
                 if (jo > ord) last = false;
             }
             if (!last) continue;
             if (li == hit_leaf) open.hit_parity = (uint32_t)cnt;
-            if (cnt & 1) open_candidate(open, li, hit_leaf, bt[i]);
+            if (cnt & 1) open_candidate(open, li, hit_leaf, ti);
         }
     }
 }
@@ -1040,7 +1134,9 @@ __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray,
     if (!TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
     if (sc.root_child_count == 0) return;
     if constexpr (sizeof(R) == 4) { // the product path: the wave walks the tree together
+        CYC_BEGIN(c_walk);
         packet_scene<MODE>(sc, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+        CYC_END(st, 0, c_walk);
         return;
     }
     // f64 validation mode: every lane walks the reference's tree on its own.

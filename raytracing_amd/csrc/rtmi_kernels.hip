@@ -28,6 +28,17 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // (second: the kernel belongs to the second pass, its FLOPs are reported in RTMI_STAT_FLOPS_SECOND as well)
 __device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *__restrict__ stats, bool second = false) {
     if (!stats) return;
+#ifdef RTMI_CYCLES
+    {
+        const int slot[4] = {RTMI_STAT_AABB_TESTS, RTMI_STAT_LEAF_TESTS, RTMI_STAT_NODE_VISITS, RTMI_STAT_FLOPS};
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long m = st.cyc[i] + (i == 3 ? __builtin_readcyclecounter() : 0ull);
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+            if ((threadIdx.x & 63) == 0) atomicAdd(&stats[slot[i]], m);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) {
         if (i == RTMI_STAT_FLOPS || i == RTMI_STAT_FLOPS_SECOND) continue;
@@ -75,11 +86,18 @@ __device__ __forceinline__ void stats_zero(Stats &s) {
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) s.c[i] = 0;
     s.flops = 0;
+#ifdef RTMI_CYCLES
+    s.cyc[0] = s.cyc[1] = s.cyc[2] = 0;
+    s.cyc[3] = 0ull - __builtin_readcyclecounter(); // + the clock at flush_stats = the cycles between
+#endif
 }
 __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) a.c[i] += b.c[i];
     a.flops += b.flops;
+#ifdef RTMI_CYCLES
+    a.cyc[0] += b.cyc[0]; a.cyc[1] += b.cyc[1]; a.cyc[2] += b.cyc[2];
+#endif
 }
 
 // One sample of Camera::multisample's loop body (camera.rs:274-276,283-285,292-296): sample 0 is the centred ray.
@@ -639,6 +657,9 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
 #pragma unroll
     for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
     st.flops = 0;
+#ifdef RTMI_CYCLES
+    st.cyc[0] = st.cyc[1] = st.cyc[2] = st.cyc[3] = 0;
+#endif
     Rng rng;
     rng.k0 = seed_lo; rng.k1 = seed_hi;
     rng_begin(rng, (uint32_t)i, 0);

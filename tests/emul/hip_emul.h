@@ -78,6 +78,7 @@ inline uint32_t __builtin_amdgcn_readlane(uint32_t x, int) { return x; }
 inline unsigned long long __ballot(bool b) { return b ? 1ull : 0ull; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline void sincospif(float x, float *s, float *c) { *s = sinf(3.14159265358979323846f * x); *c = cosf(3.14159265358979323846f * x); }
 inline void sincospi(double x, double *s, double *c) { *s = sin(3.14159265358979323846 * x); *c = cos(3.14159265358979323846 * x); }
