@@ -4,6 +4,7 @@
 #include "rtmi_launch.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -216,6 +217,7 @@ struct rtmi_scene {
     DBvh2 *bvh2 = nullptr;  // the device's own triangle BVHs (NODE_TRIBVH) and their triangles in leaf order
     DWTri *btris = nullptr;
     uint32_t n_bvh2 = 0, n_btris = 0;
+    bool bvh_has_units = false; // some DBvh2 tree has an ENT_LEAF entry
     uint32_t *quick = nullptr; // LDS records of the first top-level leaves (rtmi_device.hpp stage_scene)
     uint32_t n_quick = 0;
     DScene<float> h32;
@@ -231,6 +233,7 @@ struct Layout {
     std::vector<uint32_t> leaf_csg;    // device leaf -> innermost CSG operator
     std::vector<uint8_t> leaf_shadow;  // device leaf -> casts shadows
     std::vector<DNode> nodes;
+    std::vector<int> node_desc;        // device node -> desc node (-1 for the virtual root)
     std::vector<DCsg> csgs;
     std::vector<uint32_t> csg_l0, csg_l2; // first leaf / one past the last leaf of every CSG operator
     std::string err;
@@ -335,6 +338,7 @@ struct Layout {
     // fill device node `slot` from desc node n (a GROUP/BOUNDED or a CSG root)
     void fill(uint32_t slot, int n, bool shadow) {
         if (!check_node(n)) return;
+        node_desc[slot] = n;
         const rtmi_node &nd = d->nodes[n];
         DNode o;
         memset(&o, 0, sizeof o);
@@ -393,6 +397,7 @@ struct Layout {
         o.child_first = (uint32_t)nodes.size();
         o.child_count = (uint32_t)sub.size();
         nodes.resize(nodes.size() + sub.size());
+        node_desc.resize(nodes.size(), -1);
         nodes[slot] = o;
         for (size_t i = 0; i < sub.size(); ++i) fill(o.child_first + (uint32_t)i, sub[i].first, sub[i].second != 0);
     }
@@ -412,6 +417,7 @@ struct Layout {
         seen_leaf.assign((size_t)std::max(0, d->n_leaves), 0);
         seen_node.assign((size_t)std::max(0, d->n_nodes), 0);
         nodes.resize(1); // slot 0 = virtual root = World::objects
+        node_desc.assign(1, -1);
         DNode root;
         memset(&root, 0, sizeof root);
         root.flags = NODE_CAST_SHADOW;
@@ -436,6 +442,84 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     return RTMI_OK;
 }
 
+// forward (object -> world) affine map = inverse of the 3x4 world -> object matrix `m`, by cofactors; returns its determinant
+static double affine_forward(const double *m, double F[9], double T[3]) {
+    const double a = m[0], b = m[1], c = m[2], e = m[4], f = m[5], g = m[6], p = m[8], q = m[9], r = m[10];
+    const double det = a * (f * r - g * q) - b * (e * r - g * p) + c * (e * q - f * p);
+    const double id = 1.0 / det;
+    const double G[9] = {(f * r - g * q) * id, (c * q - b * r) * id, (b * g - c * f) * id,
+                         (g * p - e * r) * id, (a * r - c * p) * id, (c * e - a * g) * id,
+                         (e * q - f * p) * id, (b * p - a * q) * id, (a * f - b * e) * id};
+    for (int k = 0; k < 9; ++k) F[k] = G[k];
+    for (int k = 0; k < 3; ++k) T[k] = -(G[3 * k] * m[3] + G[3 * k + 1] * m[7] + G[3 * k + 2] * m[11]);
+    return det;
+}
+
+// World-space bounds (f64) the device computes for itself: of a primitive (the shape's own extent, as Shape::aabb takes it
+// from sphere.rs / cube.rs / cylinder.rs / cone.rs / triangle.rs, under the leaf's transform) and of a CSG tree - a Union is
+// within the union of its sides' bounds, an Intersection within their intersection, a Difference within its left side's.
+// A bound only ever rules rays out, so it may be tighter than the reference's (aabb.rs) without changing a hit.
+struct Bound {
+    double lo[3], hi[3];
+    static Bound none() { Bound b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } return b; }  // holds nothing
+    static Bound all() { Bound b; for (int a = 0; a < 3; ++a) { b.lo[a] = -INFINITY; b.hi[a] = INFINITY; } return b; }   // rules nothing out
+    bool empty() const { for (int a = 0; a < 3; ++a) if (!(lo[a] <= hi[a])) return true; return false; }
+    bool finite() const { for (int a = 0; a < 3; ++a) if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) return false; return true; }
+    void join(const Bound &o) { if (o.empty()) return; if (empty()) *this = none(); for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], o.lo[a]); hi[a] = std::fmax(hi[a], o.hi[a]); } }
+    void meet(const Bound &o) { for (int a = 0; a < 3; ++a) { lo[a] = std::fmax(lo[a], o.lo[a]); hi[a] = std::fmin(hi[a], o.hi[a]); } }
+};
+static Bound primitive_bound(const rtmi_leaf &s) {
+    double F[9], T[3];
+    const double det = affine_forward(s.inv, F, T);
+    if (!std::isfinite(det) || det == 0.0) return Bound::all();
+    double l[3] = {-1, -1, -1}, h[3] = {1, 1, 1};
+    std::vector<std::array<double, 3>> pts;
+    switch (s.kind) {
+    case RTMI_SPHERE: case RTMI_CUBE: break;
+    case RTMI_CYLINDER: l[1] = s.minimum; h[1] = s.maximum; break;
+    case RTMI_CONE: { const double r = std::fmax(std::fabs(s.minimum), std::fabs(s.maximum)); l[0] = l[2] = -r; h[0] = h[2] = r; l[1] = s.minimum; h[1] = s.maximum; break; }
+    case RTMI_TRIANGLE: case RTMI_SMOOTH_TRIANGLE:
+        pts.push_back({s.p1[0], s.p1[1], s.p1[2]}); pts.push_back({s.p2[0], s.p2[1], s.p2[2]}); pts.push_back({s.p3[0], s.p3[1], s.p3[2]});
+        break;
+    default: return Bound::all(); // a plane
+    }
+    if (pts.empty()) {
+        for (int a = 0; a < 3; ++a) if (!std::isfinite(l[a]) || !std::isfinite(h[a]) || l[a] > h[a]) return Bound::all();
+        for (int k = 0; k < 8; ++k) pts.push_back({(k & 1) ? h[0] : l[0], (k & 2) ? h[1] : l[1], (k & 4) ? h[2] : l[2]});
+    }
+    Bound b = Bound::none();
+    for (const auto &v : pts)
+        for (int a = 0; a < 3; ++a) {
+            const double w = F[3 * a] * v[0] + F[3 * a + 1] * v[1] + F[3 * a + 2] * v[2] + T[a];
+            if (!std::isfinite(w)) return Bound::all();
+            b.lo[a] = std::fmin(b.lo[a], w); b.hi[a] = std::fmax(b.hi[a], w);
+        }
+    return b;
+}
+// (the descriptor has been validated by Layout::run by the time this is called: indices are in range, the nodes form a tree)
+static Bound subtree_bound(const rtmi_scene_desc *d, int n) {
+    const rtmi_node &nd = d->nodes[n];
+    if (nd.kind == RTMI_NODE_LEAF) return primitive_bound(d->leaves[nd.first]);
+    if (nd.kind == RTMI_NODE_GROUP || nd.kind == RTMI_NODE_BOUNDED) {
+        Bound b = Bound::none();
+        for (int i = 0; i < nd.count; ++i) {
+            const Bound c = subtree_bound(d, d->children[nd.first + i]);
+            if (!c.empty() && !c.finite()) return Bound::all();
+            b.join(c);
+        }
+        return b;
+    }
+    const Bound l = subtree_bound(d, nd.first);
+    if (nd.kind == RTMI_NODE_CSG_DIFFERENCE) return l;
+    const Bound r = subtree_bound(d, nd.count);
+    Bound b = l;
+    if (nd.kind == RTMI_NODE_CSG_UNION) {
+        if ((!l.empty() && !l.finite()) || (!r.empty() && !r.finite())) return Bound::all();
+        b.join(r);
+    } else b.meet(r);
+    return b;
+}
+
 // World-space copies of the triangle leaves (DWTri, f32 path) in the order upload_typed numbers them (device leaf order),
 // and the NODE_ALLTRI marking of the nodes whose direct leaves are all triangles.
 static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout &L, std::vector<uint32_t> &tri_of_leaf) {
@@ -444,16 +528,8 @@ static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout
     for (size_t i = 0; i < L.leaf_orig.size(); ++i) {
         const rtmi_leaf &s = d->leaves[L.leaf_orig[i]];
         if (s.kind != RTMI_TRIANGLE && s.kind != RTMI_SMOOTH_TRIANGLE) continue;
-        // forward (object -> world) affine map = inverse of the 3x4 part of s.inv, by cofactors
-        const double *m = s.inv;
-        const double a = m[0], b = m[1], c = m[2], e = m[4], f = m[5], g = m[6], p = m[8], q = m[9], r = m[10];
-        const double det = a * (f * r - g * q) - b * (e * r - g * p) + c * (e * q - f * p);
-        const double id = 1.0 / det;
-        const double F[9] = {(f * r - g * q) * id, (c * q - b * r) * id, (b * g - c * f) * id,
-                             (g * p - e * r) * id, (a * r - c * p) * id, (c * e - a * g) * id,
-                             (e * q - f * p) * id, (b * p - a * q) * id, (a * f - b * e) * id};
-        const double T[3] = {-(F[0] * m[3] + F[1] * m[7] + F[2] * m[11]), -(F[3] * m[3] + F[4] * m[7] + F[5] * m[11]),
-                             -(F[6] * m[3] + F[7] * m[7] + F[8] * m[11])};
+        double F[9], T[3];
+        const double det = affine_forward(s.inv, F, T);
         auto lin = [&](const double *v, float *o3) { for (int k = 0; k < 3; ++k) o3[k] = (float)(F[3 * k] * v[0] + F[3 * k + 1] * v[1] + F[3 * k + 2] * v[2]); };
         DWTri w;
         memset(&w, 0, sizeof w);
@@ -480,9 +556,10 @@ static std::vector<DWTri> world_space_triangles(const rtmi_scene_desc *d, Layout
 }
 
 // ---------------------------------------------------------------------------------------------
-// host: the device's own triangle BVH (DBvh2, rtmi_device.hpp) below every maximal all-triangle subtree
+// host: the device's own BVH (DBvh2, rtmi_device.hpp) in place of a subtree of Groups / BoundingGroups.  Its items are
+// the subtree's triangles, its other primitives and its CSG roots (evaluated as a whole by csg_root)
 // ---------------------------------------------------------------------------------------------
-struct TriBvhBuilder {
+struct UnitBvhBuilder {
     struct Box {
         float lo[3], hi[3];
         void clear() { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
@@ -492,7 +569,8 @@ struct TriBvhBuilder {
             return x < 0 ? 0.0 : 2.0 * (x * y + y * z + z * x);
         }
     };
-    struct Item { Box b; float c[3]; uint32_t wtri, leaf; };
+    enum { TRI = 0, LEAF = 1, CSG = 2 };
+    struct Item { Box b; float c[3]; uint32_t kind, wtri, ref; }; // ref: device leaf (TRI, LEAF) or device node (CSG)
     struct Bin2 { Box b; int left = -1, right = -1; uint32_t first = 0, count = 0; }; // binary tree: inner (left, right) or leaf (first, count)
     std::vector<Item> items;
     std::vector<Bin2> bin;
@@ -502,14 +580,13 @@ struct TriBvhBuilder {
     int leaf_max;
     int depth = 0;
 
-    TriBvhBuilder(std::vector<DBvh2> &o2, std::vector<DWTri> &ot, const std::vector<DWTri> &w, int lm) : out2(o2), out_tris(ot), wtris(w), leaf_max(lm) {}
+    UnitBvhBuilder(std::vector<DBvh2> &o2, std::vector<DWTri> &ot, const std::vector<DWTri> &w, int lm) : out2(o2), out_tris(ot), wtris(w), leaf_max(lm) {}
 
-    // bounds of a world-space triangle as the device sees it (float corners), padded like the scene nodes' boxes
-    static Box tri_box(const DWTri &w) {
+    // a bound as the device uses it: float corners, padded like the scene nodes' boxes (Layout::make_box)
+    static Box padded(const double lo3[3], const double hi3[3]) {
         Box b;
         for (int a = 0; a < 3; ++a) {
-            const double v0 = w.p1[a], v1 = (double)w.p1[a] + w.e1[a], v2 = (double)w.p1[a] + w.e2[a];
-            const double lo = std::fmin(v0, std::fmin(v1, v2)), hi = std::fmax(v0, std::fmax(v1, v2));
+            const double lo = lo3[a], hi = hi3[a];
             const double pad = 1e-5 * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo) + 1e-6;
             float flo = (float)(lo - pad), fhi = (float)(hi + pad);
             if ((double)flo > lo - pad) flo = std::nextafterf(flo, -INFINITY);
@@ -518,13 +595,32 @@ struct TriBvhBuilder {
         }
         return b;
     }
+    // bounds of a world-space triangle as the device sees it
+    static Box tri_box(const DWTri &w) {
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            const double v0 = w.p1[a], v1 = (double)w.p1[a] + w.e1[a], v2 = (double)w.p1[a] + w.e2[a];
+            lo[a] = std::fmin(v0, std::fmin(v1, v2)); hi[a] = std::fmax(v0, std::fmax(v1, v2));
+        }
+        return padded(lo, hi);
+    }
 
-    void add(uint32_t wtri, uint32_t leaf) {
+    void add(const Box &b, uint32_t kind, uint32_t wtri, uint32_t ref) {
         Item it;
-        it.b = tri_box(wtris[wtri]);
+        it.b = b;
         for (int a = 0; a < 3; ++a) it.c[a] = 0.5f * (it.b.lo[a] + it.b.hi[a]);
-        it.wtri = wtri; it.leaf = leaf;
+        it.kind = kind; it.wtri = wtri; it.ref = ref;
         items.push_back(it);
+    }
+    void add_tri(uint32_t wtri, uint32_t leaf) { add(tri_box(wtris[wtri]), TRI, wtri, leaf); }
+    void add_unit(const Bound &b, uint32_t kind, uint32_t ref) { add(padded(b.lo, b.hi), kind, 0, ref); }
+
+    // a leaf of the tree: one item of any kind, or up to leaf_max triangles
+    bool leaf_ok(uint32_t first, uint32_t count) const {
+        if (count <= 1) return true;
+        if (count > (uint32_t)leaf_max) return false;
+        for (uint32_t i = first; i < first + count; ++i) if (items[i].kind != TRI) return false;
+        return true;
     }
 
     // binned surface-area heuristic, 16 bins on the axis where the centres spread most; a median split when that fails
@@ -539,6 +635,7 @@ struct TriBvhBuilder {
         }
         bin[me].b = b; bin[me].first = first; bin[me].count = count;
         if (count <= 1) return me;
+        const bool may_stay = leaf_ok(first, count);
         int axis = 0;
         for (int a = 1; a < 3; ++a) if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
         const float ext = chi[axis] - clo[axis];
@@ -563,15 +660,15 @@ struct TriBvhBuilder {
                 if (cost < best) { best = cost; best_k = k; }
             }
             const double leaf_cost = b.area() * count;
-            if (best_k > 0 && (count > (uint32_t)leaf_max || best + 0.5 * b.area() < leaf_cost)) {
+            if (best_k > 0 && (!may_stay || best + 0.5 * b.area() < leaf_cost)) {
                 auto it = std::partition(items.begin() + first, items.begin() + first + count, [&](const Item &x) { return bin_of(x) < best_k; });
                 mid = (uint32_t)(it - items.begin());
                 split = mid > first && mid < first + count;
             }
         }
         if (!split) {
-            if (count <= (uint32_t)leaf_max) return me; // a leaf
-            mid = first + count / 2;                      // coincident centres: any split will do
+            if (may_stay) return me;   // a leaf
+            mid = first + count / 2;   // coincident centres: any split will do
             std::nth_element(items.begin() + first, items.begin() + mid, items.begin() + first + count,
                              [&](const Item &x, const Item &y) { return x.c[axis] < y.c[axis]; });
         }
@@ -581,8 +678,14 @@ struct TriBvhBuilder {
         return me;
     }
 
-    uint32_t leaf_entry(const Bin2 &n) const { return ENT_TRIS | ((n.count - 1u) << ENT_TRI_FIRST_BITS) | (tri_base + n.first); }
     uint32_t tri_base = 0;
+    std::vector<uint32_t> tri_pos; // item -> its position among the triangle items
+    uint32_t leaf_entry(const Bin2 &n) const {
+        const Item &it = items[n.first];
+        if (it.kind == LEAF) return ENT_LEAF | it.ref;
+        if (it.kind == CSG) return it.ref; // a scene node
+        return ENT_TRIS | ((n.count - 1u) << ENT_TRI_FIRST_BITS) | (tri_base + tri_pos[n.first]);
+    }
 
     // one DBvh2 record per inner node: both children's boxes and entries
     uint32_t emit2(int node, int d) {
@@ -603,48 +706,84 @@ struct TriBvhBuilder {
         return ENT_BVH | me;
     }
 
-    // builds the tree over the items added so far and returns the stack entry of its root
+    // builds the tree over the items added so far and returns the stack entry of its root (an inner node: two items or more)
     uint32_t finish() {
-        if ((size_t)out_tris.size() + items.size() > (size_t)ENT_TRI_FIRST_MASK) return 0;
+        if (items.size() < 2 || (size_t)out_tris.size() + items.size() > (size_t)ENT_TRI_FIRST_MASK) return 0;
         tri_base = (uint32_t)out_tris.size();
         const int root = build2(0, (uint32_t)items.size());
-        for (const Item &it : items) { DWTri w = wtris[it.wtri]; w.pad = it.leaf; out_tris.push_back(w); }
+        tri_pos.assign(items.size(), 0);
+        uint32_t n = 0;
+        for (size_t i = 0; i < items.size(); ++i) {
+            tri_pos[i] = n;
+            if (items[i].kind == TRI) { DWTri w = wtris[items[i].wtri]; w.pad = items[i].ref; out_tris.push_back(w); ++n; }
+        }
         return emit2(root, 1);
     }
 };
 
-// Marks every maximal subtree of Groups / BoundingGroups that holds nothing but (usable) triangles NODE_TRIBVH and builds
-// its DBvh2 tree.  `tri_of_leaf`: device leaf -> index into wtris (or none).  Returns the deepest tree's depth in nodes.
-static int build_triangle_bvhs(Layout &L, const std::vector<DWTri> &wtris, const std::vector<uint32_t> &tri_of_leaf, std::vector<DBvh2> &bvh2,
-                               std::vector<DWTri> &btris, std::vector<int> &bvh_depth_of_node) {
+// Marks every maximal subtree of Groups / BoundingGroups whose contents all have finite bounds NODE_TRIBVH and builds its
+// DBvh2 tree: (usable) triangles, other primitives with their own world-space bounds, CSG roots with the bounds their
+// operators allow.  `tri_of_leaf`: device leaf -> index into wtris (or none).  Returns the deepest tree's depth in nodes.
+static int build_unit_bvhs(const rtmi_scene_desc *d, Layout &L, const std::vector<DWTri> &wtris, const std::vector<uint32_t> &tri_of_leaf,
+                           std::vector<DBvh2> &bvh2, std::vector<DWTri> &btris, std::vector<int> &bvh_depth_of_node) {
     const long leaf_max = std::max(1l, std::min((long)BVH_LEAF_MAX, env_long("RTMI_BVH_LEAF", RTMI_BVH_LEAF)));
     bvh_depth_of_node.assign(L.nodes.size(), 0);
-    // all_tri[n]: node n's whole subtree is triangles that have a world-space record, under properly boxed nodes
-    std::vector<int8_t> all_tri(L.nodes.size(), -1);
+    // what the tree would hold for a direct leaf / a CSG root; false: no finite bound
+    auto leaf_bound = [&](uint32_t li, Bound &b) -> bool {
+        const uint32_t t = tri_of_leaf[li];
+        if (t != 0xFFFFFFFFu) return std::isfinite(wtris[t].k) && wtris[t].k != 0.0f;
+        b = primitive_bound(d->leaves[L.leaf_orig[li]]);
+        return b.finite() && !b.empty();
+    };
+    auto csg_bound = [&](uint32_t n, Bound &b) -> bool {
+        b = subtree_bound(d, L.node_desc[n]);
+        const DNode &nd = L.nodes[n];
+        if (nd.flags & NODE_GATED) { // the reference's own box is a bound too
+            Bound r;
+            for (int a = 0; a < 3; ++a) { r.lo[a] = nd.bmin[a]; r.hi[a] = nd.bmax[a]; }
+            b.meet(r);
+        }
+        return b.empty() || b.finite(); // (empty: no ray can hit it - the tree leaves it out)
+    };
+    // able[n]: everything below node n has a finite bound
+    std::vector<int8_t> able(L.nodes.size(), -1);
     std::function<bool(uint32_t)> scan = [&](uint32_t n) -> bool {
         const DNode &nd = L.nodes[n];
-        bool ok = !(nd.flags & NODE_CSGROOT) && (nd.flags & NODE_GATED) && (nd.leaf_count + nd.child_count) > 0;
-        for (uint32_t i = 0; i < nd.leaf_count; ++i) {
-            const uint32_t t = tri_of_leaf[nd.leaf_first + i];
-            if (t == 0xFFFFFFFFu || !std::isfinite(wtris[t].k) || wtris[t].k == 0.0f) ok = false;
+        Bound b;
+        bool ok;
+        if (nd.flags & NODE_CSGROOT) ok = L.node_desc[n] >= 0 && csg_bound(n, b);
+        else {
+            ok = (nd.leaf_count + nd.child_count) > 0;
+            for (uint32_t i = 0; i < nd.leaf_count; ++i) ok = leaf_bound(nd.leaf_first + i, b) && ok;
+            for (uint32_t c = 0; c < nd.child_count; ++c) ok = scan(nd.child_first + c) && ok; // (scan every child: the marks are used below)
         }
-        for (uint32_t c = 0; c < nd.child_count; ++c) ok = scan(nd.child_first + c) && ok; // (scan every child: the marks are used below)
-        all_tri[n] = ok ? 1 : 0;
+        able[n] = ok ? 1 : 0;
         return ok;
     };
     for (uint32_t c = 0; c < L.nodes[0].child_count; ++c) scan(L.nodes[0].child_first + c);
     int deepest = 0;
-    std::function<void(uint32_t, TriBvhBuilder &)> gather = [&](uint32_t n, TriBvhBuilder &b) {
+    std::function<void(uint32_t, UnitBvhBuilder &)> gather = [&](uint32_t n, UnitBvhBuilder &b) {
         const DNode &nd = L.nodes[n];
-        for (uint32_t i = 0; i < nd.leaf_count; ++i) b.add(tri_of_leaf[nd.leaf_first + i], nd.leaf_first + i);
+        Bound bd;
+        if (nd.flags & NODE_CSGROOT) {
+            csg_bound(n, bd);
+            if (!bd.empty()) b.add_unit(bd, UnitBvhBuilder::CSG, n);
+            return;
+        }
+        for (uint32_t i = 0; i < nd.leaf_count; ++i) {
+            const uint32_t li = nd.leaf_first + i;
+            if (tri_of_leaf[li] != 0xFFFFFFFFu) b.add_tri(tri_of_leaf[li], li);
+            else { leaf_bound(li, bd); b.add_unit(bd, UnitBvhBuilder::LEAF, li); }
+        }
         for (uint32_t c = 0; c < nd.child_count; ++c) gather(nd.child_first + c, b);
     };
     std::function<void(uint32_t)> mark = [&](uint32_t n) {
         DNode &nd = L.nodes[n];
-        if (all_tri[n] == 1) {
-            TriBvhBuilder b(bvh2, btris, wtris, (int)leaf_max);
+        if (nd.flags & NODE_CSGROOT) return;
+        if (able[n] == 1) {
+            UnitBvhBuilder b(bvh2, btris, wtris, (int)leaf_max);
             gather(n, b);
-            const uint32_t entry = b.items.size() >= 4 ? b.finish() : 0u; // (a handful of triangles: the reference's node will do)
+            const uint32_t entry = b.items.size() >= 4 ? b.finish() : 0u; // (a handful of items: the reference's node will do)
             if (entry && b.depth < PACKET_STACK) {
                 nd.flags = (nd.flags | NODE_TRIBVH) & ~NODE_ALLTRI;
                 nd.csg_count = entry;
@@ -653,8 +792,7 @@ static int build_triangle_bvhs(Layout &L, const std::vector<DWTri> &wtris, const
                 return;
             }
         }
-        if (!(nd.flags & NODE_CSGROOT))
-            for (uint32_t c = 0; c < nd.child_count; ++c) mark(nd.child_first + c);
+        for (uint32_t c = 0; c < nd.child_count; ++c) mark(nd.child_first + c);
     };
     for (uint32_t c = 0; c < L.nodes[0].child_count; ++c) mark(L.nodes[0].child_first + c);
     return deepest;
@@ -841,7 +979,9 @@ template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_d
     h.n_leaves = (uint32_t)L.leaf_orig.size(); h.n_lights = (uint32_t)d->n_lights; h.n_nodes = (uint32_t)L.nodes.size();
     h.max_depth = (uint32_t)d->max_depth;
     h.root_leaf_count = L.nodes[0].leaf_count; h.root_child_first = L.nodes[0].child_first; h.root_child_count = L.nodes[0].child_count;
-    h.pad = 0;
+    h.has_units = 0;
+    for (const DNode &n : L.nodes) if (n.flags & NODE_CSGROOT) h.has_units = 1;
+    if (sizeof(R) == 4 && s->bvh_has_units) h.has_units = 1;
     h.quick = nullptr; h.n_quick = 0; h.n_lds_materials = 0; h.n_lds_lights = 0; h.pad2 = 0;
     if (sizeof(R) == 4) {
         h.quick = s->quick; h.n_quick = s->n_quick;
@@ -915,7 +1055,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     std::vector<DBvh2> bvh2;
     std::vector<DWTri> btris;
     std::vector<int> bvh_depth;
-    build_triangle_bvhs(L, wtris, tri_of_leaf, bvh2, btris, bvh_depth);
+    build_unit_bvhs(desc, L, wtris, tri_of_leaf, bvh2, btris, bvh_depth);
+    for (const DBvh2 &b : bvh2) if ((b.child[0] & ENT_KIND) == ENT_LEAF || (b.child[1] & ENT_KIND) == ENT_LEAF) s->bvh_has_units = true;
     {   // the wave's shared stack (packet_scene / packet_tris, f32 path): siblings that wait while a child is walked, plus
         // one entry per level of a triangle BVH below
         std::function<int(uint32_t)> need = [&](uint32_t slot) -> int {

@@ -57,8 +57,8 @@ constexpr uint32_t NODE_CSGROOT = 1u << 0;
 constexpr uint32_t NODE_GATED = 1u << 1;       // box is finite and proper: may be slab-tested
 constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
 constexpr uint32_t NODE_AXIS_SHIFT = 4;         // bits 4-5: 1 + the axis along which the node's two children are sorted by centre (0: no order)
-constexpr uint32_t NODE_TRIBVH = 1u << 6;      // f32 path: everything below this node is triangles (under Groups / BoundingGroups, no CSG) and has been
-                                               // rebuilt as a BVH of its own (DBvh2): csg_count = the entry of its root (ENT_BVH / ENT_TRIS)
+constexpr uint32_t NODE_TRIBVH = 1u << 6;      // f32 path: everything below this node (Groups / BoundingGroups of triangles, other primitives and CSG roots,
+                                               // all with finite bounds) has been rebuilt as a BVH of its own (DBvh2): csg_count = the entry of its root
 constexpr uint32_t NODE_ALLTRI = 1u << 3;      // not a CSG root, every direct leaf is a triangle: wtris[csg_count + i] is leaf
                                                // leaf_first + i in world space (f32 path)
 
@@ -125,8 +125,9 @@ struct alignas(64) DBvh2 { // 64 B
     uint32_t child[2];                     // stack entries (ENT_BVH | node, ENT_TRIS | count - 1 << 26 | first triangle)
     uint32_t pad[2];
 };
-// entries: bit 31 set = something of a DBvh2 tree (scene node indices have it clear)
-constexpr uint32_t ENT_BVH = 0x80000000u, ENT_TRIS = 0xC0000000u, ENT_KIND = 0xC0000000u;
+// entries (top two bits): a DBvh2 node, a run of triangles in btris, one primitive leaf (leaves[]), or - both bits clear -
+// a scene node (in a DBvh2 tree: a CSG root)
+constexpr uint32_t ENT_BVH = 0x80000000u, ENT_TRIS = 0xC0000000u, ENT_LEAF = 0x40000000u, ENT_KIND = 0xC0000000u;
 constexpr uint32_t ENT_TRI_FIRST_BITS = 26, ENT_TRI_FIRST_MASK = (1u << ENT_TRI_FIRST_BITS) - 1u;
 constexpr int BVH_LEAF_MAX = 8;   // triangles per DBvh2 leaf (3 bits of count - 1 are used of the 4 available)
 constexpr int PACKET_STACK = 64;  // entries of the wave's shared stack (the host checks the trees' depth against it)
@@ -177,7 +178,8 @@ template <typename R> struct DScene {
     const DWTri *btris;        // their triangles in leaf order, pad = the device leaf
     uint32_t n_bvh2, n_btris;  // (what packet_tris checks its entries against)
     uint32_t n_leaves, n_lights, n_nodes, max_depth;
-    uint32_t root_leaf_count, root_child_first, root_child_count, pad;
+    uint32_t root_leaf_count, root_child_first, root_child_count;
+    uint32_t has_units;        // some DBvh2 tree holds primitives that are not triangles or CSG roots, or the scene has a CSG root at all (packet_tris<MODE, true>)
     // what stage_scene copies into LDS (f32 scene only, else null / 0)
     const uint32_t *quick;     // LDS_MATS_AT dwords: the image of the block's first two tables (quick records, pattern slots)
     uint32_t n_quick;          // min(root_leaf_count, LDS_QUICK)
@@ -720,7 +722,9 @@ template <typename R, int MODE>
 __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
                          Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     CsgBuf<R> buf;
-    int k = 0;
+    int k = 0, first_i = -1; // (first_*: the smallest root so far, the earliest of equals)
+    R first_t = (R)0;
+    uint32_t first_id = 0;
     CYC_BEGIN(c_leaf);
     const uint32_t leaf_end = leaf_first + leaf_count;
     uint32_t skip_until = leaf_first, last_root = NONE; // leaves below skip_until are not tested (DGuard); the last leaf that had a root
@@ -733,8 +737,12 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i < n) {
-                    if (k < CSG_BUF) { buf.put(k, t[i], li | ((uint32_t)i << ID_ORD_SHIFT)); ++k; }
-                    else st.c[RTMI_STAT_OVERFLOW] = 1;
+                    if (k < CSG_BUF) {
+                        const uint32_t id = li | ((uint32_t)i << ID_ORD_SHIFT);
+                        if (k == 0 || t[i] < first_t) { first_t = t[i]; first_i = k; first_id = id; }
+                        buf.put(k, t[i], id);
+                        ++k;
+                    } else st.c[RTMI_STAT_OVERFLOW] = 1;
                 }
             }
         }
@@ -750,16 +758,34 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
     // Every ancestor the root reaches toggles its other flag; it reaches them bottom-up until the first that stops it, and
     // an ancestor's flags sit below its descendants' (operators are numbered parent first), so that is the HIGHEST
     // failing flag and the toggles are those at or above its pair.
+    // Ascending order (ties: buffer order, as the reference's stable sort of left ++ right, csg.rs:100-104) without
+    // marking entries: a step takes the smallest (t, index) after the step before.  The first step's entry is known from
+    // the leaf loop; later steps scan the buffer four entries at a time (the loads of a scan do not wait for each other).
     unsigned long long state = 0; // bit 2b = inl, 2b+1 = inr of CSG operator b under this root
+    R prev_t = (R)0;
+    int prev_i = -1;
+    static_assert(CSG_BUF % 4 == 0, "the scan reads whole groups of four entries");
     for (int step = 0; step < k; ++step) {
         int m = -1;
         R mt = Lim<R>::inf();
         uint32_t id = 0;
-        for (int i = 0; i < k; ++i) {
-            const uint32_t di = buf.id(i);
-            const R ti = buf.t(i);
-            if (!(di & ID_DONE) && (m < 0 || ti < mt)) { m = i; mt = ti; id = di; }
+        if (step == 0) { m = first_i; mt = first_t; id = first_id; }
+        else {
+            for (int i0 = 0; i0 < k; i0 += 4) {
+                R tj[4];
+                uint32_t dj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tj[j] = buf.t(i0 + j); dj[j] = buf.id(i0 + j); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j;
+                    const bool after = tj[j] > prev_t || (tj[j] == prev_t && i > prev_i);
+                    if (i < k && after && (m < 0 || tj[j] < mt)) { m = i; mt = tj[j]; id = dj[j]; }
+                }
+            }
         }
+        if (m < 0) break; // (a root that is not a number: no order to go on with)
+        prev_t = mt; prev_i = m;
         const uint32_t li = id & ID_LEAF_MASK;
         const DChain ch = sc.csg_chain[li];
         const unsigned long long tested = ch.zero | ch.one;
@@ -768,8 +794,7 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
         const bool keep = fail == 0ull;
         if (!keep) toggle &= ~((1ull << ((63 - __clzll((long long)fail)) & ~1)) - 1ull);
         state ^= toggle;
-        buf.set_id(m, id | ID_DONE | (keep ? ID_KEEP : 0u));
-        if (MODE == MODE_COLLECT) continue;
+        if (MODE == MODE_COLLECT) { if (keep) buf.set_id(m, id | ID_KEEP); continue; }
         if (keep && mt >= (R)0) {
             if (mt < t_limit && mt < best.t) { best.t = mt; best.leaf = li; best.ord = (id >> ID_ORD_SHIFT) & 3u; }
             break; // sorted: nothing later can be closer
@@ -944,7 +969,8 @@ __device__ __forceinline__ bool slab2(const float *lo, const float *hi, const Ra
     tnear = tmin;
     return tmin <= tmax && tmin <= t_hi && tmax >= t_lo;
 }
-template <int MODE>
+// UNITS: entries other than DBvh2 nodes and triangle runs can occur (a scene of meshes only runs the loop without them)
+template <int MODE, bool UNITS>
 __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t root, bool mine, int base, const Ray<float> &ray, V3<float> inv_d, uint32_t origin_leaf,
                             uint32_t origin_side, Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
     // (base: the entries of the shared stack below it belong to the caller, packet_scene)
@@ -975,8 +1001,26 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
             }
             if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return; // every ray of the wave is shadowed
             pop = true;
+        } else if (UNITS && (cur & ENT_KIND) == ENT_LEAF) { // a primitive that is not a triangle
+            const uint32_t li = cur & ~ENT_KIND;
+            if (li >= sc.n_leaves) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            if (in && !(MODE == MODE_ANY && best.leaf != NONE))
+                plain_leaf<float, MODE>(sc, li, sc.leaves[li], sc.leaves[li].kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return;
+            pop = true;
+        } else if (UNITS && (cur & ENT_KIND) == 0u) { // a CSG root
+            if (cur >= sc.n_nodes) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            const DNode &nd = sc.nodes[cur];
+            const uint32_t leaf_first = nd.leaf_first, leaf_count = nd.leaf_count;
+            if (!(nd.flags & NODE_CSGROOT) || leaf_first + leaf_count > sc.n_leaves) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never)
+            if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
+                st.c[RTMI_STAT_NODE_VISITS]++;
+                csg_root<float, MODE>(sc, leaf_first, leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            }
+            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return;
+            pop = true;
         } else {
-            if (!(cur & ENT_BVH) || (cur & ~ENT_KIND) >= sc.n_bvh2) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            if ((cur & ENT_KIND) != ENT_BVH || (cur & ~ENT_KIND) >= sc.n_bvh2) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
             const DBvh2 &n = sc.bvh2[cur & ~ENT_KIND];
             const float hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
             float t0 = 0, t1 = 0;
@@ -1056,12 +1100,11 @@ __device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<
         const unsigned long long hm = __ballot(h);
         if (hm == 0ull) continue;
         if (h) st.c[RTMI_STAT_NODE_VISITS]++;
-        if (flags & NODE_TRIBVH) {
-            packet_tris<MODE>(sc, nd.csg_count, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
-            continue;
-        }
-        if (flags & NODE_CSGROOT) {
-            if (h) csg_root<float, MODE>(sc, nd.leaf_first, nd.leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+        if (flags & (NODE_TRIBVH | NODE_CSGROOT)) { // the node's own BVH, or the CSG root itself as a one-entry tree (its NODE_VISITS is counted there)
+            if (h && (flags & NODE_CSGROOT)) st.c[RTMI_STAT_NODE_VISITS]--;
+            const uint32_t entry = (flags & NODE_TRIBVH) ? nd.csg_count : top;
+            if (sc.has_units) packet_tris<MODE, true>(sc, entry, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            else packet_tris<MODE, false>(sc, entry, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             continue;
         }
         // children are popped first to last; sorted children (two, by centre along an axis) last to first when most of the

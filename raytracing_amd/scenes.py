@@ -151,6 +151,67 @@ def lights_gallery(h=300, v=150, deterministic=False, random_lights=True):
     return w, _camera(h, v, (0.5, 4.5, -9), (0, 1, 0), se=2e-2, min_samples=4, deterministic=deterministic)
 
 
+def yard(h=300, v=150, deterministic=False, bounded=True):
+    """Not a reference example: one Group (or, `bounded`, the BoundingGroup tree build_bounding_tree makes of it) that holds
+    every kind of item a subtree can - spheres, cubes, closed and open finite cylinders, cones, flat and smooth triangles, a
+    nested Group, CSG unions / intersections / differences (one with a glass part) - plus an unbounded Group (an infinite
+    cylinder) next to it, so that the device's own BVH over such subtrees (DBvh2 entries of every kind) is compared with
+    the oracle's walk of the reference's tree."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(4)
+    w.add_light(rt.PointLight(rt.point(-6, 9, -8), rt.color(0.9, 0.9, 0.9)))
+    w.add_light(rt.AmbientLight(rt.color(0.1, 0.1, 0.1)))
+    w.add_item(rt.plane().with_material(rt.Phong.default().with_pattern(
+        rt.checkers_pattern(rt.color(0.3, 0.3, 0.3), rt.color(0.8, 0.8, 0.8)).with_transform(rt.translation(0.07, 0, 0.03))).with_specular(0.0).with_reflective(0.1)))
+    g = rt.group()
+    k = 0
+    for ix in range(-3, 4):
+        for iz in range(0, 4):
+            u = [_philox_uniform(0xBEEF, k, j) for j in range(6)]
+            k += 1
+            mat = rt.Phong.default().with_hsv(u[0] * 360.0, 0.7, 0.9).with_reflective(0.15 if k % 5 == 0 else 0.0)
+            place = rt.translation(ix * 1.6 + (u[1] - 0.5) * 0.4, 0, iz * 1.7 + (u[2] - 0.5) * 0.4)
+            s = 0.35 + 0.25 * u[3]
+            kind = k % 9
+            if kind == 0:
+                g.add_child(rt.sphere().with_material(mat).with_transform(place * rt.translation(0, s, 0) * rt.scaling(s, s, s)))
+            elif kind == 1:
+                g.add_child(rt.cube().with_material(mat).with_transform(place * rt.translation(0, s, 0) * rt.rotation_y(u[4] * 3.0) * rt.scaling(s, s, s)))
+            elif kind == 2:
+                g.add_child(rt.cylinder(0.0, 1.0 + u[4], True).with_material(mat).with_transform(place * rt.scaling(s, 1, s)))
+            elif kind == 3:
+                g.add_child(rt.cone(-1.0, 0.0, True).with_material(mat).with_transform(place * rt.translation(0, 1, 0) * rt.scaling(s, 1, s)))
+            elif kind == 4:
+                g.add_child(rt.cylinder(0.2, 1.2, False).with_material(mat).with_transform(place * rt.rotation_z(0.3) * rt.scaling(s, 1, s)))
+            elif kind == 5:
+                a = rt.cube().with_material(mat).with_transform(rt.scaling(s, s, s))
+                b = rt.sphere().with_material(rt.Phong.default().with_hsv(u[0] * 360.0 + 180.0, 0.7, 0.9)).with_transform(rt.translation(s * 0.6, s * 0.6, -s * 0.6) * rt.scaling(s, s, s))
+                g.add_child(rt.csg_difference(a, b).with_transform(place * rt.translation(0, s, 0) * rt.rotation_y(u[4])))
+            elif kind == 6:
+                a = rt.sphere().with_material(mat).with_transform(rt.translation(-0.3 * s, 0, 0) * rt.scaling(s, s, s))
+                b = rt.glass_sphere().with_transform(rt.translation(0.3 * s, 0, 0) * rt.scaling(s, s, s))
+                op = rt.csg_union if k % 2 else rt.csg_intersection
+                g.add_child(op(a, b).with_transform(place * rt.translation(0, s, 0)))
+            elif kind == 7:
+                sub = rt.group()
+                p0, p1, p2, p3 = rt.point(-s, 0, -s), rt.point(s, 0, -s), rt.point(0, 0, s), rt.point(0, 1.5 * s, 0)
+                for (a, b, c) in ((p0, p1, p3), (p1, p2, p3), (p2, p0, p3)):
+                    sub = sub.with_child(rt.triangle(a, b, c).with_material(mat))
+                sub = sub.with_child(rt.sphere().with_material(mat).with_transform(rt.translation(0, 1.5 * s, 0) * rt.scaling(0.2 * s, 0.2 * s, 0.2 * s)))
+                g.add_child(rt.SceneItem(sub).with_transform(place))
+            else:
+                n = rt.vector(0, 1, 0)
+                g.add_child(rt.smooth_triangle(rt.point(-s, 0.1, 0), rt.point(s, 0.1, 0), rt.point(0, 0.1 + 2 * s, 0.3 * s),
+                                               rt.vector(-0.4, 0.2, -1).normalized(), rt.vector(0.4, 0.2, -1).normalized(), n).with_material(mat).with_transform(place))
+    w.add_item(rt.build_bounding_tree(g, 2) if bounded else rt.SceneItem(g))
+    loose = rt.group().with_child(rt.cylinder().with_material(rt.Phong.default().with_rgb(0.6, 0.6, 0.7)).with_transform(
+        rt.translation(6.5, 0, 6) * rt.scaling(0.3, 1, 0.3))).with_child(rt.sphere().with_material(rt.Phong.default().with_rgb(0.9, 0.8, 0.2)).with_transform(
+        rt.translation(-6.5, 0.5, 5) * rt.scaling(0.5, 0.5, 0.5)))
+    w.add_item(rt.SceneItem(loose))
+    w.finalize_scene()
+    return w, _camera(h, v, (0.5, 5.0, -7.5), (0, 0.6, 2.5), se=2e-2, min_samples=4, deterministic=deterministic)
+
+
 def soft_shadow(h=900, v=450, deterministic=False):
     """rust/examples/soft_shadow.rs:12-59 — BASELINE config 4 (area light)."""
     w = rt.World.empty()

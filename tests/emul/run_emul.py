@@ -21,8 +21,10 @@ from raytracing_amd import abi, scenes  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 rng = np.random.default_rng(7)
 print(abi.describe())
-for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {})]:
-    world, cam = (scenes.lights_gallery if name == "gallery" else scenes.BASELINE_SCENES[name])(32, 16, **kw)
+EXTRA = {"gallery": scenes.lights_gallery, "yard": scenes.yard, "yard-group": scenes.yard}
+for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {}),
+                 ("yard", {}), ("yard-group", {"bounded": False})]:
+    world, cam = (EXTRA[name] if name in EXTRA else scenes.BASELINE_SCENES[name])(32, 16, **kw)
     f = world.flatten()
     sc = abi.Scene(world)
     o = rng.uniform(-4, 4, (n, 3)) + np.array([0, 2.0, -3.0])

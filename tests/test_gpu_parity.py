@@ -93,6 +93,28 @@ def test_baseline_scenes_one_sample(name, kw, precision):
         assert psnr(img, ref) >= 40.0
 
 
+@pytest.mark.parametrize("bounded", [True, False], ids=["bounding-tree", "plain-group"])
+@pytest.mark.parametrize("precision", [1, 0], ids=["f64", "f32"])
+@pytest.mark.parametrize("deterministic", [True, False], ids=["1spp", "adaptive"])
+def test_subtree_of_every_item_kind(bounded, precision, deterministic):
+    """scenes.yard: a Group / BoundingGroup tree of spheres, cubes, cylinders, cones, triangles, nested Groups and CSG
+    roots - every entry kind of the device's own BVH (f32) and the reference's tree walk (f64) against the oracle."""
+    world, cam = scenes.yard(192, 96, deterministic=deterministic, bounded=bounded)
+    ref, rst = orc.render(world, cam)
+    img, st = gpu_render(world, cam, precision)
+    frac, bad = frac_within_1(img, ref)
+    assert st["overflow"] == 0
+    if deterministic and precision == 1:
+        assert bad == 0, "%d pixels off by more than 1/255" % bad
+        assert {k: st[k] for k in RAY_KEYS} == {k: rst[k] for k in RAY_KEYS}
+    elif deterministic:
+        assert frac >= 0.998, "only %.5f within 1/255 (%d bad)" % (frac, bad)
+        assert psnr(img, ref) >= 40.0
+    else:
+        p = psnr(img, ref)
+        assert p >= (60.0 if precision == 1 else 35.0), "PSNR %.1f dB" % p
+
+
 STO = [("ch07", {}, 160, 80), ("ch11a", {}, 160, 80), ("ch11b", {}, 160, 80), ("soft", {}, 160, 80), ("dof", {}, 160, 80),
        # the tree scenes (BoundingGroup / CSG traversal in the second-pass kernels), as shipped
        ("teapot", {"lite": True}, 160, 80), ("teapot", {}, 128, 64), ("dice", {"nx": 2, "ny": 1}, 160, 80), ("dice", {}, 128, 64)]
