@@ -354,9 +354,10 @@ struct Stats {
     unsigned long long cyc[4]; // shader-clock cycles: 0 the tree walk (packet_scene), 1 csg_root's leaf loop, 2 its sort + filter, 3 the whole kernel
 #endif
 };
-// -DRTMI_CYCLES (a diagnostic build, tools/cycles.sh): where a wave's time goes, summed per wave into the counters
-// aabb_tests, leaf_tests, node_visits and flops INSTEAD of what those normally count.
-#ifdef RTMI_CYCLES
+// -DRTMI_CYCLES=1 or 2 (diagnostic builds, tools/cycles.py): where a wave's time goes, summed per wave into the counters
+// aabb_tests, leaf_tests, node_visits and flops INSTEAD of what those normally count.  1: the tree walk and its CSG parts;
+// 2: the three kinds of intersection query (closest hit, shadow, containers).
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 1
 #define CYC_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
 #define CYC_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
 #else
@@ -1140,7 +1141,7 @@ __device__ __forceinline__ uint32_t (*lds_node_stack())[64] {
 //   MODE_ANY    : best.leaf != NONE iff some shadow-casting root lies in [0, t_limit)
 //   MODE_COLLECT: open = which leaves the ray is inside of just in front of (t_limit, hit_leaf, hit_ord)
 template <typename R, int MODE, bool TREE>
-__device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
+__device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     // Top-level primitives: wave-uniform loop bounds.  f32: the first n_quick of them have a record in the LDS block
     // (stage_scene), fetched one leaf ahead of its test; LEAF_QUICK ones need nothing else, the others go on to their
@@ -1444,6 +1445,19 @@ template <typename R, bool TREE> __device__ __forceinline__ R leaf_ior(const DSc
         if (id < sc.n_lds_materials) return u2f_(lds_scene()[LDS_MATS_AT + id * (uint32_t)MAT_DW + 9u]); // DMaterial::ior
     }
     return sc.materials[id].ior;
+}
+
+// (-DRTMI_CYCLES=2: the cycles of the closest-hit, shadow and container queries go to counters 0, 1, 2 - tools/cycles.py)
+template <typename R, int MODE, bool TREE>
+__device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
+                         uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 2
+    const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+    traverse_body<R, MODE, TREE>(sc, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 2
+    st.cyc[MODE == MODE_CLOSEST ? 0 : MODE == MODE_ANY ? 1 : 2] += __builtin_readcyclecounter() - c0;
+#endif
 }
 
 // compute_refractive_indices (ray.rs:104-140) without the sorted list: a leaf is "open" in front of

@@ -335,11 +335,38 @@ __device__ __forceinline__ double wave_shr1(double fill, double v) {
 // of G dependent additions has no parallel form that rounds alike; it runs as a systolic pass instead: in every step
 // each lane adds its own sample to its left neighbour's partial sum; lane j holds its final value from step j on
 // (recomputing it from a final left neighbour gives the same bits).  G - 1 steps of 6 shifted additions.
+// lane l takes lane l - 1's value and the first lane of the wave (CTRL 0x138, wave_shr:1) or of every row of 16 lanes
+// (CTRL 0x111, row_shr:1) takes 0: with bound_ctrl the shift folds into the addition that uses it (v_add_f32_dpp).
+template <int CTRL> __device__ __forceinline__ float shr1_zero(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double shr1_zero(double v) {
+    const unsigned long long x = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// seq_scan for groups that are the whole wave or its rows of 16 lanes.  The head lane's addend is sum0 + c_0 and what
+// comes in from its left is 0 (0 + x = x), so every lane runs the same shifted addition in every step, one instruction
+// per component - a third of the general form's.
+template <typename R, int CTRL, int G>
+__device__ __forceinline__ void seq_scan_rows(V3<R> sum0, V3<R> sos0, V3<R> c, bool head, V3<R> &sj, V3<R> &qj) {
+    V3<R> q = squares(c);
+    if (head) { c = sum0 + c; q = sos0 + q; }
+    sj = c; qj = q;
+#pragma unroll 1
+    for (int step = 1; step < G; ++step) {
+        sj = mk<R>(shr1_zero<CTRL>(sj.x) + c.x, shr1_zero<CTRL>(sj.y) + c.y, shr1_zero<CTRL>(sj.z) + c.z);
+        qj = mk<R>(shr1_zero<CTRL>(qj.x) + q.x, shr1_zero<CTRL>(qj.y) + q.y, shr1_zero<CTRL>(qj.z) + q.z);
+    }
+}
 template <typename R>
 __device__ __forceinline__ void seq_scan(V3<R> sum0, V3<R> sos0, V3<R> c, int G, int j, V3<R> &sj, V3<R> &qj) {
+    const bool head = j == 0;
+    if (G == 64) { seq_scan_rows<R, 0x138, 64>(sum0, sos0, c, head, sj, qj); return; }
+    if (G == 16) { seq_scan_rows<R, 0x111, 16>(sum0, sos0, c, head, sj, qj); return; }
     const V3<R> q = squares(c);
     sj = sum0 + c; qj = sos0 + q;
-    const bool head = j == 0;
 #pragma unroll 1
     for (int step = 1; step < G; ++step) {
         V3<R> ts = {wave_shr1(sum0.x, sj.x), wave_shr1(sum0.y, sj.y), wave_shr1(sum0.z, sj.z)};

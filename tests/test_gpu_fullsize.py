@@ -55,6 +55,55 @@ def test_adaptive_frame_is_independent_of_sharding_and_run():
     assert bool(torch.isfinite(full).all())
 
 
+@pytest.mark.parametrize("name,min_samples", [("dice", 10), ("teapot", 10)])
+def test_tree_scenes_are_independent_of_sharding(name, min_samples):
+    """BASELINE configs 3 and 5 as shipped at full size (mesh BVH / CSG dice, adaptive): N = 1 against 4 row-tile shares,
+    bit for bit, with equal ray counts (the work counters of tree scenes depend on which rays share a wave)."""
+    import torch
+    world, cam = scenes.BASELINE_SCENES[name](H, V)
+    sc = abi.Scene(world)
+    full, st = _render(sc, cam)
+    nr, tr = 4, 8
+    out = torch.zeros_like(full)
+    tot = {k: 0 for k in abi.STAT_NAMES}
+    for r in range(nr):
+        rows = abi.rank_rows(V, r, nr, tr)
+        buf = torch.zeros((rows, H, 3), dtype=torch.float32, device="cuda")
+        stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device="cuda")
+        abi.render_device(sc, cam, abi.make_opts(rank=r, nranks=nr, tile_rows=tr), buf, stats, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out[tiles.rank_row_index(V, r, nr, tr).cuda()] = buf
+        for k, v in zip(abi.STAT_NAMES, stats.cpu().tolist()):
+            tot[k] += int(v)
+    sc.close()
+    assert torch.equal(out, full)
+    for k in ("primary", "reflection", "refraction", "shadow", "samples"):
+        assert tot[k] == st[k], k
+    assert st["primary"] == st["samples"] >= min_samples * H * V and st["overflow"] == 0 and tot["overflow"] == 0
+    assert bool(torch.isfinite(full).all())
+
+
+@pytest.mark.parametrize("name", ["dice", "teapot"])
+def test_tree_scenes_deterministic_f32_vs_f64_and_oracle_rows(name):
+    """The same two scenes at one sample per pixel: the f32 product path (the device's own BVHs, wave-cooperative walk)
+    against the f64 validation mode (the reference's tree, lane by lane), and rows of the f64 frame against the oracle."""
+    world, cam = scenes.BASELINE_SCENES[name](H, V, deterministic=True)
+    sc = abi.Scene(world)
+    f32, s32 = _render(sc, cam, precision=0)
+    f64, s64 = _render(sc, cam, precision=1)
+    sc.close()
+    assert s32["samples"] == s64["samples"] == H * V
+    a = orc.to_u8(f32.cpu().numpy().astype(np.float64)).astype(int)
+    b = orc.to_u8(f64.cpu().numpy().astype(np.float64)).astype(int)
+    d = np.abs(a - b).max(axis=2)
+    assert (d <= 1).mean() >= 0.998, float((d <= 1).mean())
+    stride = 270
+    ref, rst = orc.render(world, cam, abi.make_opts(), n_threads=16, row_stride=stride, row_offset=stride // 2)
+    rows = np.arange(stride // 2, V, stride)
+    dd = np.abs(orc.to_u8(ref[rows]).astype(int) - b[rows]).max(axis=2)
+    assert dd.max() <= 1, int(dd.max())
+
+
 def test_deterministic_frame_f32_vs_f64_and_oracle_rows():
     world, cam = scenes.chapter11a(H, V, deterministic=True)
     sc = abi.Scene(world)

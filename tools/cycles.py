@@ -1,11 +1,15 @@
-"""tools/cycles.py <scene> [w h] : where a wave's time goes, from a -DRTMI_CYCLES build of the library
-(make -C raytracing_amd/csrc BUILD=build_cyc OUT=../librtmi_cyc.so EXTRA=-DRTMI_CYCLES ../librtmi_cyc.so; RTMI_LIB=.../librtmi_cyc.so).
-In that build the counters aabb_tests / leaf_tests / node_visits / flops hold shader-clock cycles summed over waves: the tree
-walk (packet_scene, CSG roots included), csg_root's leaf loop, its sort + filter, and the whole kernel."""
+"""tools/cycles.py <scene> [w h] [stages] : where a wave's time goes, from a -DRTMI_CYCLES build of the library
+(make -C raytracing_amd/csrc BUILD=build_cyc OUT=../librtmi_cyc.so EXTRA=-DRTMI_CYCLES=1 ../librtmi_cyc.so; RTMI_LIB=.../librtmi_cyc.so).
+In that build the counters aabb_tests / leaf_tests / node_visits / flops hold shader-clock cycles summed over waves:
+  =1          the tree walk (packet_scene, CSG roots included), csg_root's leaf loop, its sort + filter, the whole kernel;
+  =2 `stages` the closest-hit queries (World::intersect + hit), the shadow queries (is_shadowed), the container queries (n1 / n2),
+              the whole kernel - the rest is camera rays, Philox, prepare_computations, lighting, sums and scheduling."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import abi, scenes
 name = sys.argv[1]
+stages = "stages" in sys.argv
+if stages: sys.argv.remove("stages")
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 for det in (True, False):
     world, cam = scenes.BASELINE_SCENES[name](w, h, deterministic=det)
@@ -13,6 +17,13 @@ for det in (True, False):
     img, st = abi.render_host(sc, cam, abi.make_opts())
     sc.close()
     tot = float(st["flops"])
+    if stages:
+        a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
+        rays = st["primary"] + st["reflection"] + st["refraction"] + st["shadow"]
+        print("%s %s: %.2f ms, %d rays | of the kernels' wave cycles: closest-hit queries %.1f %%, shadow queries %.1f %%, container queries %.1f %%, "
+              "everything else (camera ray, Philox, prepare, lighting, sums, scheduling) %.1f %%" % (
+                  name, "1spp" if det else "shipped", st["kernel_ms"], rays, 100 * a, 100 * b, 100 * c, 100 * (1 - a - b - c)))
+        continue
     print("%s %s: %.2f ms | of the kernels' wave cycles: tree walk %.1f %% (csg leaf loop %.1f %%, csg sort+filter %.1f %%), rest (top level, shading, sampling) %.1f %%" % (
         name, "1spp" if det else "shipped", st["kernel_ms"], 100 * st["aabb_tests"] / tot, 100 * st["leaf_tests"] / tot,
         100 * st["node_visits"] / tot, 100 * (1 - st["aabb_tests"] / tot)))
