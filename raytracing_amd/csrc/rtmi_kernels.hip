@@ -354,10 +354,42 @@ __device__ __forceinline__ void seq_scan_rows(V3<R> sum0, V3<R> sos0, V3<R> c, b
     V3<R> q = squares(c);
     if (head) { c = sum0 + c; q = sos0 + q; }
     sj = c; qj = q;
+    if constexpr (sizeof(R) == 4) {
+        // f32: the shift and the addition as ONE instruction per component (the compiler pairs the additions into
+        // v_pk_add_f32 and keeps six separate shifts otherwise: 9 instructions per step instead of 6).  A DPP operand must
+        // not be read within two instructions of being written: each of the six chains reads what it wrote six
+        // instructions earlier, and the s_nop covers the way into the loop.
+        float a0 = sj.x, a1 = sj.y, a2 = sj.z, a3 = qj.x, a4 = qj.y, a5 = qj.z;
+        asm volatile("s_nop 1");
 #pragma unroll 1
-    for (int step = 1; step < G; ++step) {
-        sj = mk<R>(shr1_zero<CTRL>(sj.x) + c.x, shr1_zero<CTRL>(sj.y) + c.y, shr1_zero<CTRL>(sj.z) + c.z);
-        qj = mk<R>(shr1_zero<CTRL>(qj.x) + q.x, shr1_zero<CTRL>(qj.y) + q.y, shr1_zero<CTRL>(qj.z) + q.z);
+        for (int step = 1; step < G; ++step) {
+            if constexpr (CTRL == 0x138) {
+                asm volatile("v_add_f32_dpp %0, %0, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %1, %1, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %2, %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %3, %3, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %4, %4, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %5, %5, %11 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)
+                             : "v"(c.x), "v"(c.y), "v"(c.z), "v"(q.x), "v"(q.y), "v"(q.z));
+            } else {
+                asm volatile("v_add_f32_dpp %0, %0, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %1, %1, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %3, %3, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %4, %4, %10 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %5, %5, %11 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)
+                             : "v"(c.x), "v"(c.y), "v"(c.z), "v"(q.x), "v"(q.y), "v"(q.z));
+            }
+        }
+        sj = mk<R>((R)a0, (R)a1, (R)a2); qj = mk<R>((R)a3, (R)a4, (R)a5);
+    } else {
+#pragma unroll 1
+        for (int step = 1; step < G; ++step) {
+            sj = mk<R>(shr1_zero<CTRL>(sj.x) + c.x, shr1_zero<CTRL>(sj.y) + c.y, shr1_zero<CTRL>(sj.z) + c.z);
+            qj = mk<R>(shr1_zero<CTRL>(qj.x) + q.x, shr1_zero<CTRL>(qj.y) + q.y, shr1_zero<CTRL>(qj.z) + q.z);
+        }
     }
 }
 template <typename R>
