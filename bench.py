@@ -8,8 +8,8 @@ Workload (BASELINE.json configs[1]): the reference's chapter-11a reflection/refr
     python bench.py --gpus N --steps K --warmup W            (N > 1: one process per GPU under torch.distributed.run)
 
 N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
-gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default
-3) frames are in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside
+gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default: 2,
+and 3 from 4 GPUs on, where a rank's share is short: tools/inflight.py) frames are in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside
 the library): the ends of one frame's kernels - a few waves finishing the deepest pixels - and its gather overlap
 the next frame's first pass.  Every frame is rendered completely and gathered inside the timed region; F = 1 runs
 the frames strictly one after the other.  Rank 0 prints ONE JSON line.
@@ -32,8 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device); 0 = 2, and 3 with 4 GPUs or more "
+                         "(measured shares of the headline frame, ms per frame with 2 / 3 in flight: 1/4 of it 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
     ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -134,7 +135,7 @@ def main():
     from raytracing_amd import tiles
     gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=xdev, dtype=torch.uint8 if a.gather == "rgb8" else torch.float32)
     assert gather.rows == abi.rank_rows(v, rank, world_size, a.tile_rows)
-    F = a.frames_in_flight
+    F = a.frames_in_flight if a.frames_in_flight > 0 else (3 if world_size >= 4 else 2)
     NB = max(F, 2)  # buffers: at least two, so that frame i+1 renders while frame i is gathered even with one stream
     bufs = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.float32, device=dev) for _ in range(NB)]
     bufs8 = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.uint8, device=dev) for _ in range(NB)] if a.gather == "rgb8" else None

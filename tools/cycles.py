@@ -20,9 +20,9 @@ for det in (True, False):
     if stages:
         a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
         rays = st["primary"] + st["reflection"] + st["refraction"] + st["shadow"]
-        print("%s %s: %.2f ms, %d rays | of the kernels' wave cycles: closest-hit queries %.1f %%, shadow queries %.1f %%, container queries %.1f %%, "
+        print("%s %s: %.2f ms | of the kernels' wave cycles: closest-hit queries %.1f %%, shadow queries %.1f %%, container queries %.1f %%, "
               "everything else (camera ray, Philox, prepare, lighting, sums, scheduling) %.1f %%" % (
-                  name, "1spp" if det else "shipped", st["kernel_ms"], rays, 100 * a, 100 * b, 100 * c, 100 * (1 - a - b - c)))
+                  name, "1spp" if det else "shipped", st["kernel_ms"], 100 * a, 100 * b, 100 * c, 100 * (1 - a - b - c)))
         continue
     print("%s %s: %.2f ms | of the kernels' wave cycles: tree walk %.1f %% (csg leaf loop %.1f %%, csg sort+filter %.1f %%), rest (top level, shading, sampling) %.1f %%" % (
         name, "1spp" if det else "shipped", st["kernel_ms"], 100 * st["aabb_tests"] / tot, 100 * st["leaf_tests"] / tot,

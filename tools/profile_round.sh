@@ -7,7 +7,7 @@ pre="$1"; shift
 root="${GRAFT_REPO_ROOT:-$PWD}"
 out="$root/gpurun_out/$pre"
 mkdir -p "$out"
-for spec in "ch11a shipped 6" "ch11a 1spp 12" "teapot shipped 2" "dice shipped 1"; do
+for spec in "ch11a shipped 6" "ch11a 1spp 12" "teapot shipped 2" "dice shipped 1" "soft shipped 2"; do
   set -- $spec
   scene=$1; samp=$2; steps=$3
   args="--scene $scene --sampling $samp --steps $steps --warmup 1 --frames-in-flight 1"
