@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 2
+#define RTMI_ABI_VERSION 3
 #define RTMI_EPSILON 1e-5 /* rust/src/approx_eq.rs:13 */
 
 /* ---- error codes --------------------------------------------------------------------------- */
@@ -125,6 +125,18 @@ typedef struct rtmi_light {
 } rtmi_light;
 
 /* ---- flattened `World` (world.rs:14-23 after finalize_scene, world.rs:98-105) ---------------- */
+/* A stored photon as photon_map.rs:15-20 holds it (StoredPhoton::new, then scale_power): position
+ * and direction (MINUS the direction of travel, TravellingPhoton::store, photon_map.rs:140-142) rounded to f32, the power as an f32 scale and three bytes
+ * (compress_color / decompress_color, photon_map.rs:32-47: channel = byte * scale / 255).      */
+typedef struct rtmi_photon {
+    float position[3];
+    float direction[3];
+    float power_scale;
+    uint8_t power_rgb[3];
+    uint8_t reserved;
+} rtmi_photon; /* 32 bytes */
+#define RTMI_MAX_NEAREST 128 /* the device keeps the candidates of an estimate per lane */
+
 typedef struct rtmi_scene_desc {
     int32_t abi_version; /* RTMI_ABI_VERSION */
     int32_t max_depth;   /* World::max_reflection_depth (world.rs:61: 10; the Scheme twin uses 5) */
@@ -148,6 +160,19 @@ typedef struct rtmi_scene_desc {
     int32_t n_lights;
     int32_t reserved;
     const rtmi_light *lights;       /* World::lights in insertion order                            */
+
+    /* World::photon_map (world.rs:18,186-209) for the gather of Phong::shade_hit (materials.rs:376-384).
+     * The photons as compute_photon_map collected them (world.rs:195-201), in any order: the library
+     * balances them into the reference's kd-tree itself (PhotonMap::from_vec, photon_map.rs:230-313).
+     * Tracing photons is not part of this library.  n_photons == 0 (or photon_map_enabled() false,
+     * world.rs:124-128): no map, the branch is not taken.                                          */
+    int64_t n_photons;
+    const rtmi_photon *photons;
+    int32_t n_nearest;              /* the usize next to the map (world.rs:18): photons per estimate, 1 .. RTMI_MAX_NEAREST */
+    int32_t no_direct_illumination; /* != 0: World::enable_direct_illumination(false) (world.rs:74-76): the
+                                       light loop of materials.rs:386-397 is skipped                 */
+    double max_search_radius;       /* PhotonMap::set_max_search_radius (photon_map.rs:244-246);
+                                       <= 0: unlimited (the INFINITY a new map has, photon_map.rs:241) */
 } rtmi_scene_desc;
 
 /* ---- `Camera` (camera.rs:14-32) --------------------------------------------------------------- */

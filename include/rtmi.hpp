@@ -830,6 +830,10 @@ struct FlatScene {
     std::vector<rtmi_pattern> patterns;
     std::vector<rtmi_light> lights;
     int32_t max_depth = 10;
+    std::vector<rtmi_photon> photons; // World::photon_map, if the gather is to run
+    int32_t n_nearest = 0;
+    double max_search_radius = 0.0;
+    bool direct_illumination = true;
     rtmi_scene_desc desc_;
 
     const rtmi_scene_desc *desc() {
@@ -843,6 +847,9 @@ struct FlatScene {
         desc_.n_materials = (int32_t)materials.size(); desc_.materials = materials.data();
         desc_.n_patterns = (int32_t)patterns.size(); desc_.patterns = patterns.data();
         desc_.n_lights = (int32_t)lights.size(); desc_.lights = lights.data();
+        desc_.n_photons = (int64_t)photons.size(); desc_.photons = photons.empty() ? nullptr : photons.data();
+        desc_.n_nearest = n_nearest; desc_.max_search_radius = max_search_radius;
+        desc_.no_direct_illumination = direct_illumination ? 0 : 1;
         return &desc_;
     }
 
@@ -910,10 +917,51 @@ struct FlatScene {
     }
 };
 
+// photon_map.rs:15-72 — a photon as the map stores it
+struct StoredPhoton {
+    rtmi_photon p;
+    StoredPhoton(const Point &position, const Vector &direction, const Color &power) { // StoredPhoton::new + compress_color (photon_map.rs:23-39)
+        std::memset(&p, 0, sizeof p);
+        p.position[0] = (float)position.x; p.position[1] = (float)position.y; p.position[2] = (float)position.z;
+        p.direction[0] = (float)direction.x; p.direction[1] = (float)direction.y; p.direction[2] = (float)direction.z;
+        const float x = (float)std::fmax(std::fmax(power.red, power.green), power.blue);
+        const double c[3] = {power.red, power.green, power.blue};
+        for (int k = 0; k < 3; ++k) {
+            float v = 255.0f * (float)c[k] / x;
+            v = std::fmin(std::fmax(v, 0.0f), 255.0f); // (fmax / fmin drop a NaN, as f32::max / min do)
+            p.power_rgb[k] = (uint8_t)v;
+        }
+        p.power_scale = x;
+    }
+    StoredPhoton scale_power(double s) const { StoredPhoton q = *this; q.p.power_scale *= (float)s; return q; } // photon_map.rs:61-64
+    Color power() const { // decompress_color, photon_map.rs:41-47
+        return color((double)p.power_rgb[0] * (double)p.power_scale / 255.0, (double)p.power_rgb[1] * (double)p.power_scale / 255.0,
+                     (double)p.power_rgb[2] * (double)p.power_scale / 255.0);
+    }
+};
+
 struct World {
     std::vector<Light> lights;
     std::vector<SceneItem> objects;
     uint32_t max_reflection_depth = 10; // world.rs:61
+    // world.rs:18-22.  The map is GIVEN here (set_photon_map): tracing photons (compute_photon_map, world.rs:186-273) is not
+    // part of this library; its gather in Phong::shade_hit (materials.rs:376-384) is.
+    std::vector<rtmi_photon> photon_map;
+    size_t n_nearest = 0;
+    double max_search_radius = 0.0; // (<= 0: unlimited)
+    bool direct_illumination_enabled = true, direct_photon_map_enabled = false, diffuse_photon_map_enabled = true, caustic_photon_map_enabled = true;
+    void enable_direct_illumination(bool f) { direct_illumination_enabled = f; }
+    void enable_direct_photon_map(bool f) { direct_photon_map_enabled = f; }
+    void enable_diffuse_photon_map(bool f) { diffuse_photon_map_enabled = f; }
+    void enable_caustic_photon_map(bool f) { caustic_photon_map_enabled = f; }
+    bool photon_map_enabled() const { return direct_photon_map_enabled || caustic_photon_map_enabled || diffuse_photon_map_enabled; } // world.rs:124-128
+    void drop_photon_map() { photon_map.clear(); } // world.rs:182-184
+    // what compute_photon_map leaves in the World (world.rs:203-206): the photons, each already scaled by 1 / n_photons
+    void set_photon_map(const std::vector<StoredPhoton> &photons, size_t nearest, double max_radius) {
+        photon_map.clear();
+        for (const auto &q : photons) photon_map.push_back(q.p);
+        n_nearest = nearest; max_search_radius = max_radius;
+    }
 
     static World empty() { return World(); }
     static World default_world() { // world.rs:25-53
@@ -935,6 +983,8 @@ struct World {
     std::unique_ptr<FlatScene> flatten() const {
         auto fs = std::make_unique<FlatScene>();
         fs->max_depth = (int32_t)max_reflection_depth;
+        if (photon_map_enabled()) { fs->photons = photon_map; fs->n_nearest = (int32_t)n_nearest; fs->max_search_radius = max_search_radius; }
+        fs->direct_illumination = direct_illumination_enabled;
         for (auto &l : lights) fs->lights.push_back(l.l);
         for (auto &o : objects) {
             fs->top_nodes.push_back(fs->add_item(o));

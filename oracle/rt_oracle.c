@@ -137,12 +137,25 @@ static void xl_sort(xlist *l) {
     free(tmp);
 }
 
+/* PhotonMap (photon_map.rs:224-227): the photons in kd-tree order (node i has children 2i+1, 2i+2), the flag
+ * PhotonMap::balance gave each (photon_map.rs:215-221) and where each came from in the caller's array */
+enum { KD_LEAF = 1, KD_SPLIT_X = 2, KD_SPLIT_Y = 3, KD_SPLIT_Z = 4 };
+typedef struct {
+    int64_t n;
+    rtmi_photon *photons;
+    uint8_t *flag;
+    int64_t *orig;
+    double max_search_radius;
+} pmap_t;
+
 /* per-thread context: scene, flags, counters, RNG */
 typedef struct {
     const rtmi_scene_desc *sc;
     int flags;
     uint64_t stat[RTMI_N_STATS];
     rng_t rng;
+    const pmap_t *pm; /* built at the first shade_hit that needs it, or handed in by orc_render */
+    int pm_owned;
 } ctx_t;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -709,6 +722,208 @@ void orc_lighting(const rtmi_material *m, const double *surface_color, const rtm
     to3(lighting(m, from3(surface_color), in, from3(eyev), from3(normalv), in_shadow), rgb);
 }
 
+
+/* ------------------------------------------------------------------------------------------- */
+/* Photon map: PhotonMap::from_vec / balance / find_nearest (photon_map.rs:230-380)             */
+/* ------------------------------------------------------------------------------------------- */
+/* compute_number_of_left_children (photon_map.rs:423-444) */
+int64_t orc_left_children(int64_t n) {
+    if (n <= 0) return 0;
+    if (n <= 3) return 1;
+    if (n == 4) return 2;
+    if (n <= 7) return 3;
+    int depth = (int)floor(log2((double)n));
+    int64_t full = (int64_t)1 << depth;
+    int64_t last = n - (full - 1);
+    if (last <= full / 2) return (full - 2) / 2 + last;
+    return (full - 2) / 2 + full / 2;
+}
+
+/* StoredPhoton::compress_color / decompress_color (photon_map.rs:32-47) */
+void orc_compress_color(const double *c, float *scale, uint8_t *rgb) {
+    float x = (float)fmax(fmax(c[0], c[1]), c[2]);
+    for (int k = 0; k < 3; ++k) {
+        float v = 255.0f * (float)c[k] / x;
+        v = fminf(fmaxf(v, 0.0f), 255.0f); /* (f32::max / min drop a NaN: 0 / 0 becomes 0, as Rust's do) */
+        rgb[k] = (uint8_t)v;               /* Rust `as u8`: truncation */
+    }
+    *scale = x;
+}
+void orc_decompress_color(float scale, const uint8_t *rgb, double *c) {
+    for (int k = 0; k < 3; ++k) c[k] = (double)rgb[k] * (double)scale / 255.0;
+}
+
+typedef struct { const rtmi_photon *ph; int axis; } keyctx_t;
+static const rtmi_photon *g_sort_ph; /* (qsort has no context argument; builds are serialised by pm_lock) */
+static int g_sort_axis;
+static int cmp_key(const void *a, const void *b) {
+    int64_t i = *(const int64_t *)a, j = *(const int64_t *)b;
+    float x = g_sort_ph[i].position[g_sort_axis], y = g_sort_ph[j].position[g_sort_axis];
+    if (x < y) return -1;
+    if (x > y) return 1;
+    return i < j ? -1 : (i > j ? 1 : 0); /* equal keys: the reference's partition_by_key leaves their order to its
+                                            partial sort (partial_sort.rs); index order here - unpinned for coincident coordinates */
+}
+static pthread_mutex_t pm_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* PhotonMap::balance (photon_map.rs:252-313): the median by COUNT (compute_number_of_left_children keeps the tree
+ * left-balanced) along the longest side of the cell; the cell is cut at the median photon's coordinate. */
+static void balance(const rtmi_photon *ph, int64_t *idx, int64_t n, int64_t *tree, uint8_t *flag, int64_t node, double lo[3], double hi[3]) {
+    if (n == 0) return;
+    if (n == 1) { tree[node] = idx[0]; flag[idx[0]] = KD_LEAF; return; }
+    int64_t n_left = orc_left_children(n);
+    double sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+    int axis = (sx >= sy && sx >= sz) ? 0 : ((sy >= sx && sy >= sz) ? 1 : 2);
+    g_sort_ph = ph; g_sort_axis = axis;
+    qsort(idx, (size_t)n, sizeof(int64_t), cmp_key); /* (partition_by_key(n_left, ..) needs only the n_left smallest in front) */
+    int64_t m = idx[n_left];
+    double median = (double)ph[m].position[axis];
+    tree[node] = m;
+    flag[m] = (uint8_t)(KD_SPLIT_X + axis);
+    double lhi[3] = {hi[0], hi[1], hi[2]}, rlo[3] = {lo[0], lo[1], lo[2]};
+    lhi[axis] = median; rlo[axis] = median; /* Aabb::split_x/y/z (aabb.rs:105-127) */
+    balance(ph, idx, n_left, tree, flag, 2 * (node + 1) - 1, lo, lhi);
+    balance(ph, idx + n_left + 1, n - n_left - 1, tree, flag, 2 * (node + 1), rlo, hi);
+}
+
+/* the index tree PhotonMap::balance leaves (what the reference's balance2/5/10 tests compare); lo/hi: the extent to start from */
+void orc_photon_balance(const rtmi_photon *ph, int64_t n, const double *lo, const double *hi, int64_t *tree) {
+    int64_t *idx = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    uint8_t *flag = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int64_t i = 0; i < n; ++i) { idx[i] = i; tree[i] = -1; }
+    double l[3] = {lo[0], lo[1], lo[2]}, h[3] = {hi[0], hi[1], hi[2]};
+    pthread_mutex_lock(&pm_lock);
+    balance(ph, idx, n, tree, flag, 0, l, h);
+    pthread_mutex_unlock(&pm_lock);
+    free(idx); free(flag);
+}
+
+/* PhotonMap::from_vec (photon_map.rs:230-243): extent (compute_extent, 415-421), balance, permute into tree order */
+static pmap_t *pmap_build(const rtmi_photon *ph, int64_t n, double max_search_radius) {
+    pmap_t *pm = (pmap_t *)calloc(1, sizeof(pmap_t));
+    pm->n = n;
+    pm->photons = (rtmi_photon *)malloc((size_t)(n > 0 ? n : 1) * sizeof(rtmi_photon));
+    pm->flag = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    pm->orig = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    pm->max_search_radius = max_search_radius > 0.0 ? max_search_radius : INFINITY;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], (double)ph[i].position[a]); hi[a] = fmax(hi[a], (double)ph[i].position[a]); }
+    int64_t *idx = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    uint8_t *flag = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int64_t i = 0; i < n; ++i) { idx[i] = i; pm->orig[i] = -1; }
+    pthread_mutex_lock(&pm_lock);
+    balance(ph, idx, n, pm->orig, flag, 0, lo, hi);
+    pthread_mutex_unlock(&pm_lock);
+    for (int64_t k = 0; k < n; ++k) { pm->photons[k] = ph[pm->orig[k]]; pm->flag[k] = flag[pm->orig[k]]; }
+    free(idx); free(flag);
+    return pm;
+}
+static void pmap_free(pmap_t *pm) {
+    if (!pm) return;
+    free(pm->photons); free(pm->flag); free(pm->orig); free(pm);
+}
+
+/* std::collections::BinaryHeap<SearchedPhoton> as find_nearest uses it: a max-heap on the squared distance */
+typedef struct { double d2; int64_t node; } near_t;
+typedef struct { near_t *a; int n, cap; } nheap_t;
+static void nh_push(nheap_t *h, near_t e) {
+    int i = h->n++;
+    h->a[i] = e;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!(h->a[p].d2 < h->a[i].d2)) break;
+        near_t t = h->a[p]; h->a[p] = h->a[i]; h->a[i] = t;
+        i = p;
+    }
+}
+static void nh_pop(nheap_t *h) {
+    h->a[0] = h->a[--h->n];
+    int i = 0;
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < h->n && h->a[m].d2 < h->a[l].d2) m = l;
+        if (r < h->n && h->a[m].d2 < h->a[r].d2) m = r;
+        if (m == i) break;
+        near_t t = h->a[m]; h->a[m] = h->a[i]; h->a[i] = t;
+        i = m;
+    }
+}
+
+/* PhotonMap::locate_photons (photon_map.rs:323-364): near side, far side if the plane is within the search radius and
+ * (the heap is not full or the plane is nearer than its farthest photon), then this node's own photon */
+static void locate_photons(const pmap_t *pm, int64_t node, int k, const double p[3], nheap_t *h) {
+    if (node >= pm->n) return;
+    const rtmi_photon *ph = &pm->photons[node];
+    if (2 * (node + 1) - 1 < pm->n) { /* !is_leaf (photon_map.rs:376-378) */
+        int axis = pm->flag[node] - KD_SPLIT_X;
+        double d = p[axis] - (double)ph->position[axis];
+        if (d < 0.0) {
+            locate_photons(pm, 2 * (node + 1) - 1, k, p, h);
+            if (-d < pm->max_search_radius && (h->n < k || d * d < h->a[0].d2)) locate_photons(pm, 2 * (node + 1), k, p, h);
+        } else {
+            locate_photons(pm, 2 * (node + 1), k, p, h);
+            if (d < pm->max_search_radius && (h->n < k || d * d < h->a[0].d2)) locate_photons(pm, 2 * (node + 1) - 1, k, p, h);
+        }
+    }
+    double dx = p[0] - (double)ph->position[0], dy = p[1] - (double)ph->position[1], dz = p[2] - (double)ph->position[2];
+    double d2 = dx * dx + dy * dy + dz * dz;
+    if (h->n < k || d2 < h->a[0].d2) {
+        if (h->n == k) nh_pop(h);
+        near_t e = {d2, node};
+        nh_push(h, e);
+    }
+}
+
+/* PhotonMap::find_nearest (photon_map.rs:315-321): the photons found (as indices into the CALLER's array, in the heap's
+ * order) and the squared distance of the farthest (1.0 if none).  Returns how many. */
+int orc_find_nearest(const rtmi_photon *photons, int64_t n, double max_search_radius, int n_neighbors, const double *p, int64_t *found,
+                     double *max_sq) {
+    pmap_t *pm = pmap_build(photons, n, max_search_radius);
+    nheap_t h = {(near_t *)malloc((size_t)(n_neighbors > 0 ? n_neighbors : 1) * sizeof(near_t)), 0, n_neighbors};
+    if (n_neighbors > 0) locate_photons(pm, 0, n_neighbors, p, &h);
+    *max_sq = h.n ? h.a[0].d2 : 1.0;
+    for (int i = 0; i < h.n; ++i) found[i] = pm->orig[h.a[i].node];
+    int cnt = h.n;
+    free(h.a);
+    pmap_free(pm);
+    return cnt;
+}
+
+static const pmap_t *ctx_pmap(ctx_t *cx) {
+    if (!cx->pm && cx->sc->n_photons > 0 && cx->sc->photons) {
+        cx->pm = pmap_build(cx->sc->photons, cx->sc->n_photons, cx->sc->max_search_radius);
+        cx->pm_owned = 1;
+    }
+    return cx->pm;
+}
+static void ctx_done(ctx_t *cx) {
+    if (cx->pm_owned) pmap_free((pmap_t *)cx->pm);
+    cx->pm = NULL; cx->pm_owned = 0;
+}
+
+/* the photon-map term of Phong::shade_hit (materials.rs:376-384) */
+static v3 photon_estimate(ctx_t *cx, const comps_t *c, v3 surface_color) {
+    const pmap_t *pm = ctx_pmap(cx);
+    int k = cx->sc->n_nearest;
+    if (!pm || k <= 0) return V(0, 0, 0);
+    nheap_t h = {(near_t *)malloc((size_t)k * sizeof(near_t)), 0, k};
+    double p[3] = {c->point.x, c->point.y, c->point.z};
+    locate_photons(pm, 0, k, p, &h);
+    double square_radius = h.n ? h.a[0].d2 : 1.0;
+    v3 total = V(0, 0, 0);
+    for (int i = 0; i < h.n; ++i) { /* (the fold runs over the heap's array, as BinaryHeap::into_iter does) */
+        const rtmi_photon *ph = &pm->photons[h.a[i].node];
+        double pw[3];
+        orc_decompress_color(ph->power_scale, ph->power_rgb, pw);
+        double w = fmax(vdot(c->normalv, V((double)ph->direction[0], (double)ph->direction[1], (double)ph->direction[2])), 0.0);
+        total = vadd(total, vmul(V(pw[0], pw[1], pw[2]), w));
+    }
+    free(h.a);
+    v3 sc = V(surface_color.x * total.x, surface_color.y * total.y, surface_color.z * total.z);
+    return vmul(sc, 1.0 / (3.14159265358979323846 * square_radius)); /* (Color / f64 is scale(1 / x), color.rs:145-149) */
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* World::color_at / is_shadowed / Phong::shade_hit                                             */
 /* ------------------------------------------------------------------------------------------- */
@@ -756,14 +971,14 @@ static v3 refracted_color(ctx_t *cx, const rtmi_material *m, const comps_t *c, i
     return vmul(col, m->transparency);
 }
 
-/* Phong::shade_hit (materials.rs:371-412); the photon-map branch (376-384) is out of scope:
- * World::photon_map is None unless compute_photon_map ran (world.rs:62). */
+/* Phong::shade_hit (materials.rs:371-412), with the photon-map branch (376-384) when the scene carries a map */
 static v3 shade_hit(ctx_t *cx, const comps_t *c, int remaining) {
     const rtmi_scene_desc *sc = cx->sc;
     const rtmi_material *m = &sc->materials[sc->leaves[c->leaf].material];
     v3 surface_color = surface_color_at(cx, c);
     v3 surface = V(0, 0, 0);
-    for (int li = 0; li < sc->n_lights; ++li) {
+    if (sc->n_photons > 0 && sc->photons) surface = vadd(surface, photon_estimate(cx, c, surface_color));
+    for (int li = 0; li < (sc->no_direct_illumination ? 0 : sc->n_lights); ++li) { /* world.direct_illumination_enabled(), materials.rs:386 */
         const rtmi_light *l = &sc->lights[li];
         double u1 = 0, u2 = 0;
         if (light_draws(l->kind)) { u1 = rng_next(&cx->rng); u2 = rng_next(&cx->rng); }
@@ -807,6 +1022,7 @@ int orc_color_at(const rtmi_scene_desc *scene, const double *origin, const doubl
     v3 c;
     int hit = color_at(&cx, r, remaining, RTMI_STAT_PRIMARY, &c);
     to3(c, rgb);
+    ctx_done(&cx);
     return hit;
 }
 
@@ -866,6 +1082,7 @@ int orc_shade_explicit(const rtmi_scene_desc *scene, const double *origin, const
     if (rgb) to3(col, rgb);
     if (rec) { memset(rec, 0, sizeof *rec); fill_record(&cx, &c, rec); }
     xl_free(&xs);
+    ctx_done(&cx);
     return 1;
 }
 
@@ -957,11 +1174,13 @@ typedef struct {
     double *rgb;
     volatile int *next_row;
     uint64_t stat[RTMI_N_STATS];
+    const pmap_t *pm; /* the frame's photon map, built once by orc_render */
 } job_t;
 
 static void *render_worker(void *arg) {
     job_t *j = (job_t *)arg;
     ctx_t cx; ctx_init(&cx, j->sc, j->flags);
+    cx.pm = j->pm;
     cx.rng.seed = j->opts ? j->opts->seed : 0;
     int max_samples = j->opts ? j->opts->max_samples : 0;
     for (;;) {
@@ -986,7 +1205,9 @@ int orc_render(const rtmi_scene_desc *scene, const rtmi_camera *cam, const rtmi_
     volatile int next_row = 0;
     job_t *jobs = (job_t *)calloc((size_t)n_threads, sizeof(job_t));
     pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    pmap_t *pm = (scene->n_photons > 0 && scene->photons) ? pmap_build(scene->photons, scene->n_photons, scene->max_search_radius) : NULL;
     for (int i = 0; i < n_threads; ++i) {
+        jobs[i].pm = pm;
         jobs[i].sc = scene; jobs[i].cam = cam; jobs[i].opts = opts; jobs[i].flags = flags;
         jobs[i].row_stride = row_stride; jobs[i].row_offset = row_offset;
         jobs[i].rgb = rgb_out; jobs[i].next_row = &next_row;
@@ -1000,6 +1221,7 @@ int orc_render(const rtmi_scene_desc *scene, const rtmi_camera *cam, const rtmi_
             for (int k = 0; k < RTMI_N_STATS; ++k) stats[k] += jobs[i].stat[k];
     }
     free(jobs); free(th);
+    pmap_free(pm);
     return 0;
 }
 

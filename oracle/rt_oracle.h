@@ -16,7 +16,7 @@
  *   materials.rs:239-336,371-412   lights.rs:89-95,153-160,230-243,292-294,353-362,438-453
  *   shapes/mod.rs:108-124,252-322,399-477   sphere.rs:47-71  plane.rs:35-52  cube.rs:33-85
  *   cylinder.rs:36-128  cone.rs:36-148  triangle.rs:33-45,141-143,233-265  csg.rs:26-32,97-129
- *   aabb.rs:45-141  pattern.rs:7-35,51-53  color.rs:53-68
+ *   aabb.rs:45-141  pattern.rs:7-35,51-53  color.rs:53-68  photon_map.rs:15-72,224-444 (the map and its gather; not the tracing of photons)
  * Randomness: the reference draws from rand::thread_rng (OS-seeded, unreproducible; "parity
  * unpinned" for sample positions).  Both this oracle and the HIP path draw from one seeded
  * Philox4x32-10 stream, counter = (pixel, sample, draw), and replace rand_distr's rejection
@@ -91,6 +91,16 @@ int orc_aabb_intersect(const double *bmin, const double *bmax, const double *ori
 void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out4);
 double orc_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k);
 /* Color::to_u8 (color.rs:53-60). */
+/* Photon map (photon_map.rs): compute_number_of_left_children (423-444), compress / decompress_color (32-47), the index
+ * tree PhotonMap::balance leaves (252-313; lo / hi: the extent it starts from), PhotonMap::from_vec + find_nearest
+ * (230-243, 315-364; found: indices into `photons`, returns how many). */
+int64_t orc_left_children(int64_t n);
+void orc_compress_color(const double *c, float *scale, uint8_t *rgb);
+void orc_decompress_color(float scale, const uint8_t *rgb, double *c);
+void orc_photon_balance(const rtmi_photon *photons, int64_t n, const double *lo, const double *hi, int64_t *tree);
+int orc_find_nearest(const rtmi_photon *photons, int64_t n, double max_search_radius, int n_neighbors, const double *p,
+                     int64_t *found, double *max_sq);
+
 void orc_to_u8(const double *rgb, int64_t n_values, uint8_t *out);
 
 #ifdef __cplusplus

@@ -257,7 +257,34 @@ PYBIND11_MODULE(_front, m) {
         .def_readwrite("max_reflection_depth", &World::max_reflection_depth)
         .def_readwrite("objects", &World::objects).def_readwrite("lights", &World::lights)
         .def("set_object", [](World &w, size_t i, const SceneItem &it) { w.objects.at(i) = it; })
+        .def("enable_direct_illumination", &World::enable_direct_illumination).def("enable_direct_photon_map", &World::enable_direct_photon_map)
+        .def("enable_diffuse_photon_map", &World::enable_diffuse_photon_map).def("enable_caustic_photon_map", &World::enable_caustic_photon_map)
+        .def("photon_map_enabled", &World::photon_map_enabled).def("drop_photon_map", &World::drop_photon_map)
+        .def("set_photon_map", &World::set_photon_map, py::arg("photons"), py::arg("n_nearest"), py::arg("max_search_radius") = 0.0)
+        .def("n_photons", [](const World &w) { return w.photon_map.size(); })
+        // (positions float32[n,3], directions float32[n,3], power_scale float32[n], power_rgb uint8[n,3]: the stored photons as arrays)
+        .def("set_photon_arrays", [](World &w, py::array_t<float, py::array::c_style | py::array::forcecast> pos,
+                                     py::array_t<float, py::array::c_style | py::array::forcecast> dir,
+                                     py::array_t<float, py::array::c_style | py::array::forcecast> scale,
+                                     py::array_t<uint8_t, py::array::c_style | py::array::forcecast> rgb, size_t nearest, double max_radius) {
+            const size_t n = (size_t)scale.size();
+            if ((size_t)pos.size() != 3 * n || (size_t)dir.size() != 3 * n || (size_t)rgb.size() != 3 * n) throw std::invalid_argument("photon arrays disagree in length");
+            w.photon_map.assign(n, rtmi_photon{});
+            for (size_t i = 0; i < n; ++i) {
+                rtmi_photon &q = w.photon_map[i];
+                for (int k = 0; k < 3; ++k) { q.position[k] = pos.data()[3 * i + k]; q.direction[k] = dir.data()[3 * i + k]; q.power_rgb[k] = rgb.data()[3 * i + k]; }
+                q.power_scale = scale.data()[i];
+            }
+            w.n_nearest = nearest; w.max_search_radius = max_radius;
+        }, py::arg("positions"), py::arg("directions"), py::arg("power_scale"), py::arg("power_rgb"), py::arg("n_nearest"), py::arg("max_search_radius") = 0.0)
         .def("flatten", [](const World &w) { return w.flatten(); });
+
+    py::class_<StoredPhoton>(m, "StoredPhoton")
+        .def(py::init<const Point &, const Vector &, const Color &>())
+        .def("scale_power", &StoredPhoton::scale_power).def("power", &StoredPhoton::power)
+        .def("power_scale", [](const StoredPhoton &q) { return q.p.power_scale; })
+        .def("power_rgb", [](const StoredPhoton &q) { return std::vector<int>{q.p.power_rgb[0], q.p.power_rgb[1], q.p.power_rgb[2]}; })
+        .def("position", [](const StoredPhoton &q) { return std::vector<float>{q.p.position[0], q.p.position[1], q.p.position[2]}; });
 
     py::class_<DeviceScene>(m, "DeviceScene")
         .def(py::init<const World &>())

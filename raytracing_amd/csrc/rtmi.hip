@@ -212,6 +212,8 @@ struct rtmi_scene {
     DCsg *csgs = nullptr;
     DGuard *csg_guard = nullptr;
     DChain *csg_chain = nullptr;
+    DPhoton *photons = nullptr; // World::photon_map in kd-tree order
+    uint32_t n_photons = 0;
     uint32_t *leaf_orig = nullptr;
     DWTri *wtris = nullptr;
     DBvh2 *bvh2 = nullptr;  // the device's own triangle BVHs (NODE_TRIBVH) and their triangles in leaf order
@@ -798,6 +800,61 @@ static int build_unit_bvhs(const rtmi_scene_desc *d, Layout &L, const std::vecto
     return deepest;
 }
 
+// ---------------------------------------------------------------------------------------------
+// host: PhotonMap::from_vec (photon_map.rs:230-313) - the photons into the reference's left-balanced kd-tree, heap order
+// ---------------------------------------------------------------------------------------------
+static long long kd_left_children(long long n) { // compute_number_of_left_children, photon_map.rs:423-444
+    if (n <= 0) return 0;
+    if (n <= 3) return 1;
+    if (n == 4) return 2;
+    if (n <= 7) return 3;
+    int depth = 0;
+    while ((2ll << depth) <= n) ++depth; // floor(log2 n)
+    const long long full = 1ll << depth, last = n - (full - 1);
+    return last <= full / 2 ? (full - 2) / 2 + last : (full - 2) / 2 + full / 2;
+}
+static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) {
+    std::vector<DPhoton> out((size_t)n);
+    std::vector<uint32_t> idx((size_t)n);
+    for (long long i = 0; i < n; ++i) idx[(size_t)i] = (uint32_t)i;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}; // compute_extent, photon_map.rs:415-421
+    for (long long i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], (double)ph[i].position[a]); hi[a] = std::fmax(hi[a], (double)ph[i].position[a]); }
+    struct Job { long long first, count, node; double lo[3], hi[3]; };
+    std::vector<Job> todo;
+    Job root = {0, n, 0, {lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+    todo.push_back(root);
+    auto put = [&](long long node, uint32_t i, uint32_t flag) {
+        DPhoton &q = out[(size_t)node];
+        for (int k = 0; k < 3; ++k) { q.pos[k] = ph[i].position[k]; q.dir[k] = ph[i].direction[k]; }
+        q.scale = ph[i].power_scale;
+        q.rgbf = (uint32_t)ph[i].power_rgb[0] | ((uint32_t)ph[i].power_rgb[1] << 8) | ((uint32_t)ph[i].power_rgb[2] << 16) | (flag << 24);
+    };
+    while (!todo.empty()) {
+        const Job j = todo.back();
+        todo.pop_back();
+        if (j.count == 0 || j.node >= n) continue;
+        if (j.count == 1) { put(j.node, idx[(size_t)j.first], KD_LEAF); continue; }
+        const long long n_left = kd_left_children(j.count);
+        const double sx = j.hi[0] - j.lo[0], sy = j.hi[1] - j.lo[1], sz = j.hi[2] - j.lo[2];
+        const int axis = (sx >= sy && sx >= sz) ? 0 : ((sy >= sx && sy >= sz) ? 1 : 2); // photon_map.rs:270-294
+        // partition_by_key(n_left, ..): the n_left smallest keys in front, the next one at n_left (equal keys: by index -
+        // the reference leaves them to its partial sort)
+        std::nth_element(idx.begin() + j.first, idx.begin() + j.first + n_left, idx.begin() + j.first + j.count, [&](uint32_t a, uint32_t b) {
+            const float x = ph[a].position[axis], y = ph[b].position[axis];
+            return x < y || (x == y && a < b);
+        });
+        const uint32_t m = idx[(size_t)(j.first + n_left)];
+        const double median = (double)ph[m].position[axis];
+        put(j.node, m, (uint32_t)(KD_SPLIT_X + axis));
+        Job l = j, r = j;
+        l.count = n_left; l.node = 2 * (j.node + 1) - 1; l.hi[axis] = median;            // Aabb::split_*, aabb.rs:105-127
+        r.first = j.first + n_left + 1; r.count = j.count - n_left - 1; r.node = 2 * (j.node + 1); r.lo[axis] = median;
+        todo.push_back(l); todo.push_back(r);
+    }
+    return out;
+}
+
 template <typename R>
 static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A, std::vector<uint32_t> *quick = nullptr) {
     std::vector<DLeaf<R>> leaves(L.leaf_orig.size());
@@ -971,7 +1028,10 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
 
 template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_desc *d, const Layout &L, const DeviceArrays<R> &A, DScene<R> &h) {
     h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
-    h.nodes = s->nodes; h.csgs = s->csgs; h.csg_guard = s->csg_guard; h.csg_chain = s->csg_chain; h.leaf_orig = s->leaf_orig;
+    h.nodes = s->nodes; h.csgs = s->csgs; h.csg_guard = s->csg_guard; h.csg_chain = s->csg_chain;
+    h.photons = s->n_photons ? s->photons : nullptr; h.n_photons = s->n_photons; h.n_nearest = s->n_photons ? (uint32_t)d->n_nearest : 0u;
+    h.no_direct = d->no_direct_illumination ? 1u : 0u; h.pad3 = 0;
+    h.photon_radius = d->max_search_radius > 0.0 ? (R)d->max_search_radius : (R)INFINITY; h.leaf_orig = s->leaf_orig;
     h.wtris = sizeof(R) == 4 ? s->wtris : nullptr;
     h.bvh2 = sizeof(R) == 4 ? s->bvh2 : nullptr;
     h.n_bvh2 = sizeof(R) == 4 ? s->n_bvh2 : 0u; h.n_btris = sizeof(R) == 4 ? s->n_btris : 0u;
@@ -1011,6 +1071,11 @@ static int validate(const rtmi_scene_desc *d) {
     for (int i = 0; i < d->n_patterns; ++i)
         if (d->patterns[i].kind < RTMI_PATTERN_STRIPE || d->patterns[i].kind > RTMI_PATTERN_XYZ)
             return fail(RTMI_ERR_INVALID, "pattern " + std::to_string(i) + ": bad kind (closures cannot cross the ABI)");
+    if (d->n_photons < 0 || (d->n_photons > 0 && !d->photons)) return fail(RTMI_ERR_INVALID, "photon map: negative count or null array");
+    if (d->n_photons >= (1ll << 30)) return fail(RTMI_ERR_UNSUPPORTED, "photon map: the limit is 2^30 - 1 photons");
+    if (d->n_photons > 0 && (d->n_nearest < 1 || d->n_nearest > RTMI_MAX_NEAREST))
+        return fail(RTMI_ERR_UNSUPPORTED, "photon map: n_nearest must be in [1, " + std::to_string(RTMI_MAX_NEAREST) + "]");
+    if (d->n_photons > 0 && std::isnan(d->max_search_radius)) return fail(RTMI_ERR_INVALID, "photon map: max_search_radius is not a number");
     for (int i = 0; i < d->n_lights; ++i)
         if (d->lights[i].kind < RTMI_LIGHT_POINT || d->lights[i].kind > RTMI_LIGHT_BEAM) return fail(RTMI_ERR_INVALID, "light " + std::to_string(i) + ": bad kind");
     return RTMI_OK;
@@ -1030,7 +1095,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->photons); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -1077,6 +1142,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
     if (rc == RTMI_OK) rc = upload(&s->csg_guard, L.guards());
     if (rc == RTMI_OK) rc = upload(&s->csg_chain, L.chains());
+    if (rc == RTMI_OK && desc->n_photons > 0) { s->n_photons = (uint32_t)desc->n_photons; rc = upload(&s->photons, balance_photons(desc->photons, desc->n_photons)); }
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
     std::vector<uint32_t> quick;
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &quick);
@@ -1197,7 +1263,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     const int first_samples = std::max(1, (o && o->max_samples > 0 && o->max_samples < c->min_samples) ? o->max_samples : c->min_samples);
     // (Both instantiations round every sample alike - Makefile, -ffp-contract=on - so the choice may look at this rank's
     // share of the frame without the image depending on the sharding: tests/test_gpu_first_pass_modes.py.)
-    const bool spread = !state && first_samples > 1 && first_samples <= 64 && (long long)rp.n_tiles < (long long)s->num_cu * 12 * spread_below(); // (a progressive pass resumes pixels: one lane each)
+    const bool spread = !state && s->n_photons == 0 && first_samples > 1 && first_samples <= 64 && (long long)rp.n_tiles < (long long)s->num_cu * 12 * spread_below(); // (a progressive pass resumes pixels: one lane each)
     rp.first = (uint32_t)first_samples;
     rp.group = spread ? (uint32_t)first_samples : 1u;
     rp.ppw = 64u / rp.group;
@@ -1209,7 +1275,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     grid = std::max(std::min(grid, (int)((visits + 2) / 3)), (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * 12));
     bool f64 = o && o->precision == RTMI_PRECISION_F64;
     if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
-    const bool tree = s->h32.root_child_count != 0;
+    const bool tree = s->h32.root_child_count != 0 || s->n_photons != 0; // (a photon map: the tree kind's kernels, which take flat scenes too)
     DCamera<double> cam = make_camera<double>(c, o);
     unsigned long long *ds = (unsigned long long *)d_stats;
     // The open-ended part of Camera::multisample (camera.rs:290-299) runs over work queues - if it can be reached at all.

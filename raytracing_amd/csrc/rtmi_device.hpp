@@ -162,6 +162,15 @@ struct DGuard { uint32_t start, skip; }; // skip == 0: no record at this leaf
 // CsgOp::eval (csg.rs:26-32) needs clear / set for a root of this leaf to pass (see csg_root).
 struct alignas(16) DChain { unsigned long long zero, one; };
 
+// A photon of the map (photon_map.rs:15-20) as the device reads it: 32 bytes, the bytes of the compressed power and the
+// flag PhotonMap::balance gave the photon (photon_map.rs:215-221) in one word.
+enum { KD_LEAF = 1, KD_SPLIT_X = 2, KD_SPLIT_Y = 3, KD_SPLIT_Z = 4 };
+struct DPhoton {
+    float pos[3], dir[3], scale;
+    uint32_t rgbf; // r | g << 8 | b << 16 | kd flag << 24
+};
+constexpr int PHOTON_STACK = 64; // entries of the search's stack: two per level of a tree of at most 2^30 photons
+
 template <typename R> struct DScene {
     const DLeaf<R> *leaves;
     const DTri<R> *tris;
@@ -172,6 +181,9 @@ template <typename R> struct DScene {
     const DCsg *csgs;
     const DGuard *csg_guard;   // one per leaf
     const DChain *csg_chain;   // one per leaf
+    const DPhoton *photons;    // World::photon_map in kd-tree order (node i: children 2i + 1, 2i + 2), or null
+    uint32_t n_photons, n_nearest, no_direct, pad3;
+    R photon_radius;           // PhotonMap::max_search_radius (+inf: unlimited)
     const uint32_t *leaf_orig; // device leaf -> index in rtmi_scene_desc.leaves
     const DWTri *wtris;        // one per entry of tris (f32 scene only, else null)
     const DBvh2 *bvh2;         // the NODE_TRIBVH trees (f32 scene only)
@@ -377,6 +389,7 @@ constexpr uint32_t F_AABB = 20;        // aabb.rs:46-70,134-135
 constexpr uint32_t F_PREPARE = 75, F_SMOOTH_NORMAL = 9; // ray.rs:77-84, shapes/mod.rs:262-264,320-321
 constexpr uint32_t F_LIGHT_RAY = 60, F_LIGHT_SHADOWED = 20, F_LIGHT_OMNI = 3; // lights.rs:90-94, materials.rs:256-285
 constexpr uint32_t F_COMBINE = 15;     // materials.rs:399-410
+constexpr uint32_t F_PHOTON_VISIT = 9, F_PHOTON_GATHER = 17, F_PHOTON_ESTIMATE = 8; // photon_map.rs:355 / materials.rs:379-381 / 382
 constexpr uint32_t F_SCHLICK = 20;     // ray.rs:200-218
 constexpr uint32_t F_REFRACT_DIR = 25; // materials.rs:319-326
 constexpr uint32_t F_WEIGHT = 3;       // materials.rs:305,332
@@ -1553,10 +1566,89 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
     return sh.leaf != NONE;
 }
 
+// The photon-map term of Phong::shade_hit (materials.rs:376-384): PhotonMap::find_nearest (photon_map.rs:315-364) with the
+// recursion of locate_photons unrolled onto a stack (stage 0: descend to the near side; 1: back from it, the far side if
+// its plane is within the search radius and nearer than the farthest candidate; 2: the node's own photon, after both
+// sides as in the reference) and its BinaryHeap as two per-lane arrays; then the fold over the photons found.
+template <typename R>
+__device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V3<R> normalv, V3<R> surface_color, Stats &st) {
+    const uint32_t n = sc.n_photons;
+    const int k = (int)min(sc.n_nearest, (uint32_t)RTMI_MAX_NEAREST);
+    R hd[RTMI_MAX_NEAREST];
+    uint32_t hn[RTMI_MAX_NEAREST];
+    int cnt = 0;
+    uint32_t stk[PHOTON_STACK];
+    int sp = 0;
+    const R pc[3] = {p.x, p.y, p.z};
+    if (n > 0 && k > 0) stk[sp++] = 0u;
+    uint32_t visited = 0;
+    while (sp > 0) {
+        const uint32_t e = stk[--sp];
+        const uint32_t node = e >> 2, stage = e & 3u;
+        if (node >= n) continue;
+        const DPhoton &ph = sc.photons[node];
+        const uint32_t left = 2u * (node + 1u) - 1u;
+        bool self = stage == 2u || left >= n; // (is_leaf, photon_map.rs:376-378)
+        if (!self) {
+            const uint32_t axis = min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u);
+            const R d = pc[axis] - (R)ph.pos[axis];
+            const uint32_t near = d < (R)0 ? left : left + 1u, far = d < (R)0 ? left + 1u : left;
+            if (sp + 2 > PHOTON_STACK) { st.c[RTMI_STAT_OVERFLOW] = 1; self = true; } // (never: the tree is balanced)
+            else if (stage == 0u) { stk[sp++] = (node << 2) | 1u; stk[sp++] = near << 2; }
+            else if ((d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < hd[0])) { stk[sp++] = (node << 2) | 2u; stk[sp++] = far << 2; }
+            else self = true;
+        }
+        if (self) {
+            const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
+            const R d2 = dx * dx + dy * dy + dz * dz;
+            ++visited;
+            if (cnt < k || d2 < hd[0]) {
+                if (cnt == k) { // BinaryHeap::pop: the last entry to the root, then down
+                    --cnt;
+                    hd[0] = hd[cnt]; hn[0] = hn[cnt];
+                    int i = 0;
+                    for (;;) {
+                        const int l = 2 * i + 1, r = l + 1;
+                        int m = i;
+                        if (l < cnt && hd[m] < hd[l]) m = l;
+                        if (r < cnt && hd[m] < hd[r]) m = r;
+                        if (m == i) break;
+                        const R td = hd[m]; hd[m] = hd[i]; hd[i] = td;
+                        const uint32_t tn = hn[m]; hn[m] = hn[i]; hn[i] = tn;
+                        i = m;
+                    }
+                }
+                int i = cnt++; // BinaryHeap::push: at the end, then up
+                hd[i] = d2; hn[i] = node;
+                while (i > 0) {
+                    const int q = (i - 1) / 2;
+                    if (!(hd[q] < hd[i])) break;
+                    const R td = hd[q]; hd[q] = hd[i]; hd[i] = td;
+                    const uint32_t tn = hn[q]; hn[q] = hn[i]; hn[i] = tn;
+                    i = q;
+                }
+            }
+        }
+    }
+    const R square_radius = cnt ? hd[0] : (R)1; // (unwrap_or(1.0), photon_map.rs:318)
+    V3<R> total = mk<R>(0, 0, 0);
+    for (int i = 0; i < cnt; ++i) {
+        const DPhoton &ph = sc.photons[min(hn[i], n - 1u)];
+        const R w = max_(dot(normalv, mk<R>((R)ph.dir[0], (R)ph.dir[1], (R)ph.dir[2])), (R)0);
+        const R x = (R)ph.scale;
+        // decompress_color (photon_map.rs:41-47): byte * scale / 255
+        const V3<R> power = mk<R>(div_((R)(ph.rgbf & 255u) * x, (R)255), div_((R)((ph.rgbf >> 8) & 255u) * x, (R)255), div_((R)((ph.rgbf >> 16) & 255u) * x, (R)255));
+        total = total + power * w;
+    }
+    st.flops += visited * F_PHOTON_VISIT + (uint32_t)cnt * F_PHOTON_GATHER + F_PHOTON_ESTIMATE;
+    return had(surface_color, total) * rcp_((R)3.14159265358979323846 * square_radius); // (Color / f64 is scale(1 / x), color.rs:145-149)
+}
+
 // World::color_at (world.rs:115-118) with Phong::shade_hit (materials.rs:371-412) unrolled into a loop:
 // shade_hit is linear in its children's colours, so each ray carries the product of the factors
 // above it ("weight") and adds weight * (clipped direct light + emissive) to the sample.
-template <typename R, bool TREE>
+// PHOTON: the scene may carry a photon map (kernels of their own: the search's per-lane arrays are not for the others to pay)
+template <typename R, bool TREE, bool PHOTON = false>
 __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
     const R EPS = (R)RTMI_EPSILON;
     V3<R> acc = mk<R>(0, 0, 0);
@@ -1602,7 +1694,11 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                 }
             }
             V3<R> surface = mk<R>(0, 0, 0);
-            for (uint32_t li = 0; li < sc.n_lights; ++li) { // materials.rs:386-397
+            if constexpr (PHOTON) {
+                if (sc.n_photons) surface = photon_estimate(sc, c.point, c.normalv, surface_color, st); // materials.rs:376-384
+            }
+            const uint32_t n_direct = (PHOTON && sc.no_direct) ? 0u : sc.n_lights; // world.direct_illumination_enabled(), materials.rs:386
+            for (uint32_t li = 0; li < n_direct; ++li) { // materials.rs:386-397
                 Incoming<R> in;
                 bool staged = false;
                 if constexpr (staged_v<R, TREE>) {

@@ -101,13 +101,13 @@ __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 }
 
 // One sample of Camera::multisample's loop body (camera.rs:274-276,283-285,292-296): sample 0 is the centred ray.
-template <typename R, bool TREE>
+template <typename R, bool TREE, bool PHOTON = false>
 __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<double> &cam, Rng &rng, Stats &st, int px, int py, uint32_t s) {
     rng_begin(rng, (uint32_t)(py * cam.hsize + px), s);
     st.c[RTMI_STAT_SAMPLES]++;
     st.flops += camera_flops(cam);
     Ray<R> ray = camera_ray<R>(cam, px, py, s != 0, rng);
-    return color_at<R, TREE>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
+    return color_at<R, TREE, PHOTON>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
 }
 
 // Further samples the stopping rule is expected to ask of a pixel with these running sums.  The reference's sum of squares
@@ -207,7 +207,7 @@ __device__ __forceinline__ void keep_state(DPixelState<R> *__restrict__ state, s
 // out.  The others - a few per cent of the frame, needing anything from one to thousands of further samples - are
 // appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
-template <typename R, bool TREE, bool SPREAD>
+template <typename R, bool TREE, bool SPREAD, bool PHOTON = false>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
         bool go = SPREAD ? true : (valid && need_more(cam, sum, sos, (R)cnt, cnt)), queued = false, full = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
         while (go) { // wave-uniform until the pixels' sums hold `first` samples
             V3<R> c = mk<R>(0, 0, 0);
-            if (!SPREAD || valid) c = take_sample<R, TREE>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
+            if (!SPREAD || valid) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
             // camera.rs:277-278: BOTH sums start from the first sample itself - the sum of squares from c, not from c * c -
             // and only the later samples enter it squared (camera.rs:286,297)
             if (grouped) { // the owner adds its group's samples up in sample order, like the reference's loop
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *
 // A pixel's samples are always summed in rounds of 64 (light: RTMI_LIGHT_ROUNDS rounds of 64 / RTMI_LIGHT_BATCH first)
 // counted from its own first-pass count, whoever computes them and however many were computed ahead: the image does
 // not depend on queue order, sharding, promotion or the prediction, bit for bit.
-template <typename R, bool TREE>
+template <typename R, bool TREE, bool PHOTON = false>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                       const DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
             stats_zero(ls);
-            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE>(sc, cam, rng, ls, ox, oy, s);
+            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, ox, oy, s);
             // the pixel's sums after each of the group's samples, added up one after the other like the reference's loop
             V3<R> sj, qj;
             seq_scan(sum0, sos0, c, G, j, sj, qj);
@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
 // The units of pass `pass` (see resample_kernel): each wave pops batches of units, takes every unit's 64 samples and
 // leaves colours and counters in the unit's DChunk.
 constexpr int UNIT_BATCH_MAX = 16;
-template <typename R, bool TREE>
+template <typename R, bool TREE, bool PHOTON = false>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
                                                    const DWorkItem<R> *__restrict__ wk_heavy, const uint32_t *__restrict__ wk_unit_pixel,
                                                    DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass) {
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
             stats_zero(ls);
-            if (!(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE>(sc, cam, rng, ls, px, py, s);
+            if (!(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, px, py, s);
             DChunk<R> *ch = wk_chunks + (u0 + i);
             ch->col[0][lane] = c.x; ch->col[1][lane] = c.y; ch->col[2][lane] = c.z;
             ch->st[0][lane] = (ls.c[RTMI_STAT_PRIMARY] & 0xFFu) | ((ls.c[RTMI_STAT_SAMPLES] & 0xFFu) << 8) | (min(ls.c[RTMI_STAT_OVERFLOW], 0xFFFFu) << 16);
@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units
 #endif // RTMI_HOST_EMUL
 
 // World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays)
-template <typename R>
+template <typename R, bool PHOTON = false>
 __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
                                                    const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
     Comps<R> c;
     c.point = mk<R>(0, 0, 0); c.normalv = c.point; c.eyev = c.point; c.inside = false; c.side_plus = false; c.n1 = 1; c.n2 = 1;
     int rem = remaining ? remaining[i] : (int)sc.max_depth;
-    V3<R> col = color_at<R, true>(sc, ray, rem, rng, st, &h, &c);
+    V3<R> col = color_at<R, true, PHOTON>(sc, ray, rem, rng, st, &h, &c);
     if (rgb) { rgb[3 * i] = (double)col.x; rgb[3 * i + 1] = (double)col.y; rgb[3 * i + 2] = (double)col.z; }
     if (recs) {
         rtmi_hit_record r;
@@ -782,7 +782,9 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
     DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
     DPixelState<RTMI_REAL> *state = (DPixelState<RTMI_REAL> *)state_;
     const bool spread = rp.group > 1;
-    if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
+    const bool photon = sc.n_photons != 0; // (kernels of their own, tree kind, one lane per pixel: the host chooses tree = true, no spread)
+    if (photon) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
+    else if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
     else if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
     else if (spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
     else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
@@ -792,11 +794,13 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
         const int pass = l <= RTMI_SPEC_PASSES ? l : -1;
         if (pass < 0 && RTMI_SPEC_PASSES == 0) break;
         if (pass > 0) {
-            if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            if (photon) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            else if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
             else hipLaunchKernelGGL((units_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
             hipLaunchKernelGGL(sum_up_kernel<RTMI_REAL>, dim3(grid_resample), dim3(64), 0, st, cam, out, stats, wk.hdr, wk.heavy, wk.final_idx, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, state);
         } else {
-            if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
+            if (photon) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
+            else if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
             else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
         }
     }
@@ -809,7 +813,8 @@ void launch_render_kernel<RTMI_REAL>(bool, int, int, hipStream_t, const DScene<R
 template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,
                                     const double *origins, const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
-    hipLaunchKernelGGL(trace_kernel<RTMI_REAL>, dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
+    if (sc.n_photons) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
+    else hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
 }
 template <>
 void launch_camera_rays_kernel<RTMI_REAL>(int grid, const DCamera<double> &cam, uint32_t seed_lo, uint32_t seed_hi, long long n,

@@ -212,6 +212,26 @@ def yard(h=300, v=150, deterministic=False, bounded=True):
     return w, _camera(h, v, (0.5, 5.0, -7.5), (0, 0.6, 2.5), se=2e-2, min_samples=4, deterministic=deterministic)
 
 
+def photon_room(h=300, v=150, deterministic=False, direct=True):
+    """Not a reference example (examples/photon-map.rs traces 75 M photons, which this library does not do): a floor, a back
+    wall, a matt sphere, a mirror sphere and a glass sphere under one point light, to which a test attaches a photon map
+    (World.set_photon_arrays) so that the gather of Phong::shade_hit (materials.rs:376-384) runs on primary, reflected and
+    refracted hits.  `direct` False: World::enable_direct_illumination(false), the map is all the light there is."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(4)
+    w.add_light(rt.PointLight(rt.point(-3, 6, -4), rt.color(0.8, 0.8, 0.8)))
+    w.add_item(rt.plane().with_material(rt.Phong.default().with_rgb(0.8, 0.8, 0.75).with_specular(0.0)))
+    w.add_item(rt.plane().with_transform(rt.translation(0, 0, 5) * rt.rotation_x(PI / 2.0)).with_material(
+        rt.Phong.default().with_pattern(rt.stripe_pattern(rt.color(0.7, 0.3, 0.3), rt.color(0.3, 0.3, 0.7)).with_transform(rt.translation(0.11, 0, 0))).with_specular(0.0)))
+    w.add_item(rt.sphere().with_transform(rt.translation(-1.6, 1, 1)).with_material(rt.Phong.default().with_rgb(0.9, 0.6, 0.2).with_specular(0.1)))
+    w.add_item(rt.sphere().with_transform(rt.translation(0.9, 0.8, 0.2) * rt.scaling(0.8, 0.8, 0.8)).with_material(
+        rt.Phong.default().with_rgb(0.1, 0.1, 0.1).with_reflective(0.8).with_specular(0.6)))
+    w.add_item(rt.glass_sphere().with_transform(rt.translation(-0.2, 0.5, -1.6) * rt.scaling(0.5, 0.5, 0.5)))
+    w.enable_direct_illumination(direct)
+    w.finalize_scene()
+    return w, _camera(h, v, (0, 2.2, -6.5), (0, 0.8, 0), se=2e-2, min_samples=4, deterministic=deterministic)
+
+
 def soft_shadow(h=900, v=450, deterministic=False):
     """rust/examples/soft_shadow.rs:12-59 — BASELINE config 4 (area light)."""
     w = rt.World.empty()

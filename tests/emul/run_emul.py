@@ -21,9 +21,19 @@ from raytracing_amd import abi, scenes  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 rng = np.random.default_rng(7)
 print(abi.describe())
-EXTRA = {"gallery": scenes.lights_gallery, "yard": scenes.yard, "yard-group": scenes.yard}
+import photon_cases  # noqa: E402
+
+
+def photon_room(h, v, **kw):
+    """scenes.photon_room with a map of 3000 photons attached: the gather of materials.rs:376-384 in trace_kernel<R, true>"""
+    world, cam = scenes.photon_room(h, v, **kw)
+    photon_cases.attach(world, photon_cases.direct_photons(world, (-3, 6, -4), 3000, 3), 24, 0.6)
+    return world, cam
+
+
+EXTRA = {"gallery": scenes.lights_gallery, "yard": scenes.yard, "yard-group": scenes.yard, "photons": photon_room, "photons-only": photon_room}
 for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {}),
-                 ("yard", {}), ("yard-group", {"bounded": False})]:
+                 ("yard", {}), ("yard-group", {"bounded": False}), ("photons", {}), ("photons-only", {"direct": False})]:
     world, cam = (EXTRA[name] if name in EXTRA else scenes.BASELINE_SCENES[name])(32, 16, **kw)
     f = world.flatten()
     sc = abi.Scene(world)

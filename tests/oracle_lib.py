@@ -44,6 +44,12 @@ def lib():
         L.orc_aabb_intersect.argtypes = [C.c_void_p] * 6
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_to_u8.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_left_children.restype = C.c_int64
+        L.orc_left_children.argtypes = [C.c_int64]
+        L.orc_compress_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_decompress_color.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_photon_balance.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_find_nearest.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -157,3 +163,56 @@ def camera_ray(camera, px, py, sample=0, seed=0x5EED):
     d = np.zeros(3)
     lib().orc_camera_ray(cam.address(), seed, px, py, sample, o.ctypes.data, d.ctypes.data)
     return o, d
+
+
+# --- photon map (photon_map.rs) ---------------------------------------------------------------------------------
+PHOTON_DTYPE = np.dtype([("position", np.float32, 3), ("direction", np.float32, 3), ("power_scale", np.float32), ("power_rgb", np.uint8, 3),
+                         ("reserved", np.uint8)])  # rtmi_photon, 32 bytes
+
+
+def left_children(n):
+    return int(lib().orc_left_children(n))
+
+
+def compress_color(c):
+    scale = C.c_float(0)
+    rgb = np.zeros(3, dtype=np.uint8)
+    cc = v3(c)
+    lib().orc_compress_color(cc.ctypes.data, C.byref(scale), rgb.ctypes.data)
+    return float(scale.value), rgb
+
+
+def decompress_color(scale, rgb):
+    out = np.zeros(3)
+    r = np.ascontiguousarray(rgb, dtype=np.uint8)
+    lib().orc_decompress_color(C.c_float(scale), r.ctypes.data, out.ctypes.data)
+    return out
+
+
+def make_photons(positions, directions=None, powers=None):
+    """StoredPhoton::new for every row (photon_map.rs:23-30): f32 position / direction, compressed power."""
+    positions = np.asarray(positions, dtype=np.float64).reshape(-1, 3)
+    n = len(positions)
+    ph = np.zeros(n, dtype=PHOTON_DTYPE)
+    assert ph.itemsize == 32
+    ph["position"] = positions.astype(np.float32)
+    ph["direction"] = (np.tile([0.0, 0.0, 1.0], (n, 1)) if directions is None else np.asarray(directions, dtype=np.float64).reshape(-1, 3)).astype(np.float32)
+    powers = np.ones((n, 3)) if powers is None else np.asarray(powers, dtype=np.float64).reshape(-1, 3)
+    for i in range(n):
+        ph["power_scale"][i], ph["power_rgb"][i] = compress_color(powers[i])
+    return ph
+
+
+def photon_balance(photons, lo, hi):
+    tree = np.zeros(len(photons), dtype=np.int64)
+    lo, hi = v3(lo), v3(hi)
+    lib().orc_photon_balance(photons.ctypes.data, len(photons), lo.ctypes.data, hi.ctypes.data, tree.ctypes.data)
+    return tree.tolist()
+
+
+def find_nearest(photons, n_neighbors, p, max_search_radius=0.0):
+    found = np.zeros(max(n_neighbors, 1), dtype=np.int64)
+    msq = C.c_double(0)
+    pp = v3(p)
+    k = lib().orc_find_nearest(photons.ctypes.data, len(photons), float(max_search_radius), int(n_neighbors), pp.ctypes.data, found.ctypes.data, C.byref(msq))
+    return found[:k].tolist(), float(msq.value)

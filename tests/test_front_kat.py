@@ -235,7 +235,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = abi.lib()
     for s in declared:
         assert getattr(lib, s) is not None
-    assert abi.describe().startswith("rtmi abi=2 target=gfx950")
+    assert abi.describe().startswith("rtmi abi=3 target=gfx950")
 
 
 def test_c_abi_struct_sizes_match():
@@ -264,6 +264,27 @@ def test_scene_validation_errors_are_loud():
     w.set_max_reflection_depth(99)
     with pytest.raises(abi.RtmiError, match="max_depth"):
         abi.Scene(w)
+
+
+def test_photon_map_validation_and_stored_photon():
+    """The photon fields of the descriptor are checked before any device is touched; StoredPhoton::new / scale_power / power of the
+    front end are the reference's (photon_map.rs:23-64,733-750)."""
+    import numpy as np
+    w = rt.World.default()
+    pos = np.zeros((3, 3), dtype=np.float32); dirs = np.zeros((3, 3), dtype=np.float32)
+    for bad in (0, 129):
+        w.set_photon_arrays(pos, dirs, np.ones(3, dtype=np.float32), np.full((3, 3), 255, dtype=np.uint8), bad, 0.5)
+        with pytest.raises(abi.RtmiError, match="n_nearest"):
+            abi.Scene(w)
+    w.drop_photon_map()
+    assert w.n_photons() == 0 and w.photon_map_enabled()
+    q = rt.StoredPhoton(rt.point(1, 2, 3), rt.vector(0, 0, 1), rt.color(1e2, 1e3, 1e-3))
+    assert q.power_rgb() == [25, 255, 0] and abs(q.power_scale() - 1e3) < 1e-3
+    c = q.power()
+    assert abs(c.red - 98.03922) < 1e-4 and abs(c.green - 1e3) < 1e-3 and c.blue == 0.0
+    assert abs(q.scale_power(0.5).power().green - 500.0) < 1e-3
+    w.set_photon_map([q, q.scale_power(0.25)], 2, 1.5)
+    assert w.n_photons() == 2
 
 
 def test_cpp_example_compiles_and_fails_loudly_without_a_gpu(tmp_path):
