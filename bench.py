@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device); 0 = 2, and 3 with 4 GPUs or more "
                          "(measured shares of the headline frame, ms per frame with 2 / 3 in flight: 1/4 of it 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
-    ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice")
+    ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice (BASELINE configurations) | photons | yard")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--sampling", default="shipped", choices=["shipped", "1spp"])
@@ -56,7 +56,9 @@ def parse():
 def workload_name(a):
     names = {"ch07": "chapter-07 spheres, hard shadows", "ch11a": "chapter-11a reflection/refraction, depth 5",
              "ch11b": "chapter-11b water reflection/refraction, depth 5", "teapot": "chapter-15 teapot mesh in host-built BVH",
-             "soft": "soft_shadow sphere light", "dof": "depth-of-field thin lens", "dice": "chapter-16 CSG dice + lens"}
+             "soft": "soft_shadow sphere light", "dof": "depth-of-field thin lens", "dice": "chapter-16 CSG dice + lens",
+             "photons": "photon_room with a map of 2 M photons, 100 nearest per estimate (not a BASELINE configuration)",
+             "yard": "yard of every item kind (not a BASELINE configuration)"}
     samp = "adaptive multisampling as shipped" if a.sampling == "shipped" else "1 centred sample per pixel"
     if a.max_samples:
         samp += " capped at %d samples/pixel" % a.max_samples
@@ -126,7 +128,7 @@ def main():
             dist.init_process_group("gloo")
     xdev = dev if a.backend == "nccl" else torch.device("cpu")  # where the exchanged tensors live
 
-    build = scenes.BASELINE_SCENES[a.scene]
+    build = scenes.BASELINE_SCENES.get(a.scene) or scenes.EXTRA_SCENES[a.scene]
     world, cam = build(a.width, a.height, deterministic=(a.sampling == "1spp"))
     scene = abi.Scene(world)
     prec = 0 if a.precision == "f32" else 1
@@ -240,7 +242,7 @@ def main():
         fl2 = float(one_call["flops_second"])
         fl1 = float(one_call["flops"]) - fl2
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        tree = "tree" if a.scene in ("teapot", "dice") else "flat"
+        tree = "tree" if a.scene in ("teapot", "dice", "yard") else ("tree, photon map" if a.scene == "photons" else "flat")
         kernels = {
             "render_kernel<%s, %s> (first pass)" % (a.precision, tree): {"ms": ms1, "algorithmic_flops": fl1, "achieved": tf(fl1, ms1)},
             "resample_kernel<%s, %s> + units_kernel + sum_up_kernel (second pass)" % (a.precision, tree): {"ms": ms2, "algorithmic_flops": fl2, "achieved": tf(fl2, ms2)},

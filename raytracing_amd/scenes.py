@@ -232,6 +232,30 @@ def photon_room(h=300, v=150, deterministic=False, direct=True):
     return w, _camera(h, v, (0, 2.2, -6.5), (0, 0.8, 0), se=2e-2, min_samples=4, deterministic=deterministic)
 
 
+def synthetic_photons(n, seed=7):
+    """A map for photon_room without tracing anything: n photons where the room's point light would leave direct ones - on
+    the floor and the back wall, seeded - as the four arrays World.set_photon_arrays takes.  (numpy only: the tests' maps
+    come from the oracle's ray casts, tests/photon_cases.py; this one is for measuring the gather on millions of photons.)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_floor = int(0.7 * n)
+    pos = np.empty((n, 3), dtype=np.float64)
+    pos[:n_floor] = np.column_stack([rng.uniform(-8, 8, n_floor), np.zeros(n_floor), rng.uniform(-8, 5, n_floor)])
+    pos[n_floor:] = np.column_stack([rng.uniform(-8, 8, n - n_floor), rng.uniform(0, 8, n - n_floor), np.full(n - n_floor, 5.0)])
+    to_light = np.array([-3.0, 6.0, -4.0]) - pos
+    to_light /= np.linalg.norm(to_light, axis=1, keepdims=True)
+    scale = (rng.uniform(0.5, 1.5, n) * 250.0 / n).astype(np.float32)
+    rgb = np.tile(np.array([255, 242, 229], dtype=np.uint8), (n, 1))
+    return pos.astype(np.float32), to_light.astype(np.float32), scale, rgb
+
+
+def photon_room_with_map(h=300, v=150, deterministic=False, n_photons=2_000_000, n_nearest=100, max_search_radius=0.3):
+    """photon_room + synthetic_photons: the photon-map gather at the scale of examples/photon-map.rs's 100 nearest photons"""
+    w, cam = photon_room(h, v, deterministic=deterministic)
+    w.set_photon_arrays(*synthetic_photons(n_photons), n_nearest, max_search_radius)
+    return w, cam
+
+
 def soft_shadow(h=900, v=450, deterministic=False):
     """rust/examples/soft_shadow.rs:12-59 — BASELINE config 4 (area light)."""
     w = rt.World.empty()
@@ -480,6 +504,8 @@ SCHEME_GOLDENS = {
     "chapter13": (scheme_chapter13, True),
     "chapter16": (scheme_chapter16, False),
 }
+
+EXTRA_SCENES = {"photons": photon_room_with_map, "yard": yard}  # (bench.py --scene takes these too; not BASELINE configurations)
 
 BASELINE_SCENES = {
     "ch07": chapter07,
