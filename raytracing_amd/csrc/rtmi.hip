@@ -1270,7 +1270,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     const unsigned long long visits = ((unsigned long long)rp.n_tiles * 64u + rp.ppw - 1) / rp.ppw;
     if (visits > 0x7FFFFFFFull) return fail(RTMI_ERR_UNSUPPORTED, "frame too large for one call");
     rp.n_visits = (uint32_t)visits;
-    const int per_cu = (!spread && first_samples >= 4) ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU;
+    const int per_cu = (int)env_long("RTMI_GRID_PER_CU", (!spread && first_samples >= 4) ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU);
     int grid = (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * per_cu);
     grid = std::max(std::min(grid, (int)((visits + 2) / 3)), (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * 12));
     bool f64 = o && o->precision == RTMI_PRECISION_F64;

@@ -234,7 +234,18 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
     // (SPREAD = the second way; a template parameter because one kernel for both ways spilled 10 more registers in the first)
     const uint32_t g = SPREAD ? rp.group : 1u, slot_k = (uint32_t)lane / g, sidx = (uint32_t)lane - slot_k * g;
     const uint32_t first = SPREAD ? g : rp.first; // samples in a pixel's sums when its fate is first decided
-    for (uint32_t visit = blockIdx.x; visit < rp.n_visits; visit += gridDim.x) {
+    // Visits are taken from a counter (in the order of the frame's tiles) when the call has work memory: a wave that drew
+    // cheap tiles goes on to the next ones instead of ending while others still have theirs before them.
+    const bool draw = RTMI_DRAW_VISITS && !SPREAD && wk_hdr != nullptr; // (a spread visit is one sample long: the counter would be its cost)
+    __shared__ uint32_t next_visit;
+    for (uint32_t visit = blockIdx.x;; ) {
+        if (draw) {
+            if (lane == 0) next_visit = atomicAdd(&wk_hdr[WK_VISIT_HEAD], 1u);
+            __syncthreads();
+            visit = next_visit;
+            __syncthreads();
+        }
+        if (visit >= rp.n_visits) break;
         const unsigned long long q = (unsigned long long)visit * rp.ppw + slot_k;
         const int tile = (int)(q >> 6), in_tile = (int)(q & 63u);
         int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
@@ -312,6 +323,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
             out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
             keep_state<R>(state, (size_t)ly * cam.hsize + x, sum, sos, cnt);
         }
+        if (!draw) visit += gridDim.x;
     }
     flush_stats(st, stats);
 }

@@ -27,9 +27,12 @@ constexpr size_t WORK_HEADER_BYTES = 32768; // 64 counters, then the unit passes
 #ifndef RTMI_SPEC_MAX
 #define RTMI_SPEC_MAX 64 // most units a pixel is given in one pass
 #endif
+#ifndef RTMI_DRAW_VISITS
+#define RTMI_DRAW_VISITS 1 // the first pass's waves draw their visits from a counter instead of striding over them
+#endif
 constexpr int WK_MAX_LAUNCHES = 9; // RTMI_SPEC_PASSES + 2
 enum {
-    WK_LIGHT_COUNT = 0, WK_HEAVY_COUNT = 1, WK_FINAL_COUNT = 2, WK_FINAL_HEAD = 3, WK_HEAVY_HEAD = 4, WK_PROMO_COUNT = 5, WK_LIGHT_HEAD = 6,
+    WK_LIGHT_COUNT = 0, WK_HEAVY_COUNT = 1, WK_FINAL_COUNT = 2, WK_FINAL_HEAD = 3, WK_HEAVY_HEAD = 4, WK_PROMO_COUNT = 5, WK_LIGHT_HEAD = 6, WK_VISIT_HEAD = 7,
     WK_UNIT_COUNT = 8   // + pass (1 .. RTMI_SPEC_PASSES)
 };
 static_assert(RTMI_SPEC_PASSES >= 0 && RTMI_SPEC_PASSES <= 7, "header layout");
