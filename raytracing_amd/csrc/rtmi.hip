@@ -1210,16 +1210,15 @@ static int check_camera(const rtmi_camera *c) {
 #ifndef RTMI_INLANE_MAX
 #define RTMI_INLANE_MAX 4096 // ... and so does one that has taken this many past the first samples
 #endif
-// With a thin lens (camera.rs:118-137: aperture_size > 0) the 64 samples of ONE pixel all pass through the pixel's point on
-// the focal plane and meet the same objects, while neighbouring pixels' rays start all over the lens: there the second
-// pass's wide rounds are the coherent ones (depth-of-field frame: 261 ms with these limits, 284 ms with the two above; the
-// soft-shadow frame, no lens: 67 ms against 51 ms).  Tree scenes keep the short limits too: their samples are several times
-// as long, and a lane that runs thousands of them is the end of the launch (dice frame, one call alone: 278 ms / 388 ms).
-#ifndef RTMI_INLANE_NEED_LENS
-#define RTMI_INLANE_NEED_LENS 192
+// Tree scenes keep short limits: their samples are several times as long (a dice sample is 8 slow rays), a lane's samples
+// run one after the other, and a lane that runs hundreds of them holds its wave - and the launch - for as long as they take
+// (dice frame with the long limits: 287 ms against 248, one call alone 393 against 253; teapot: no difference).  The
+// soft-shadow frame, flat: 67 ms with the short limits, 48 ms with the long ones; depth of field 244 / 231 ms.
+#ifndef RTMI_INLANE_NEED_TREE
+#define RTMI_INLANE_NEED_TREE 192
 #endif
-#ifndef RTMI_INLANE_MAX_LENS
-#define RTMI_INLANE_MAX_LENS 384
+#ifndef RTMI_INLANE_MAX_TREE
+#define RTMI_INLANE_MAX_TREE 384
 #endif
 #ifndef RTMI_INLANE_MIN_VISITS
 #define RTMI_INLANE_MIN_VISITS 8 // ... all of which applies to frames with at least this many tiles per resident wave
@@ -1291,9 +1290,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     // in a row would be the end of the launch, so everything past the first samples goes to the queues.
     // (the environment replaces the constants, read at every call: tuning sweeps, and the tests that hold the policies
     // against each other bit for bit)
-    const bool lens = c->aperture_size > 0.0 || tree; // (the short limits; see RTMI_INLANE_NEED_LENS)
-    const long env_keep = env_long("RTMI_KEEP_LANES", RTMI_KEEP_LANES), env_need = env_long("RTMI_INLANE_NEED", lens ? RTMI_INLANE_NEED_LENS : RTMI_INLANE_NEED),
-               env_max = env_long("RTMI_INLANE_MAX", lens ? RTMI_INLANE_MAX_LENS : RTMI_INLANE_MAX), env_visits = env_long("RTMI_INLANE_MIN_VISITS", RTMI_INLANE_MIN_VISITS);
+    const long env_keep = env_long("RTMI_KEEP_LANES", RTMI_KEEP_LANES), env_need = env_long("RTMI_INLANE_NEED", tree ? RTMI_INLANE_NEED_TREE : RTMI_INLANE_NEED),
+               env_max = env_long("RTMI_INLANE_MAX", tree ? RTMI_INLANE_MAX_TREE : RTMI_INLANE_MAX), env_visits = env_long("RTMI_INLANE_MIN_VISITS", RTMI_INLANE_MIN_VISITS);
     const bool inlane = open_ended && !spread && (long long)rp.n_tiles >= (long long)s->num_cu * 12 * env_visits;
     rp.keep_lanes = inlane ? (uint32_t)std::max(1l, std::min(64l, env_keep)) : 65u;
     rp.inlane_need = (uint32_t)std::max(0l, env_need);
