@@ -207,7 +207,7 @@ __device__ __forceinline__ void keep_state(DPixelState<R> *__restrict__ state, s
 // out.  The others - a few per cent of the frame, needing anything from one to thousands of further samples - are
 // appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
-template <typename R, bool TREE, bool SPREAD, bool PHOTON = false>
+template <typename R, bool TREE, bool SPREAD, bool PHOTON = false, bool DRAW = false>
 __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
@@ -234,16 +234,15 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
     // (SPREAD = the second way; a template parameter because one kernel for both ways spilled 10 more registers in the first)
     const uint32_t g = SPREAD ? rp.group : 1u, slot_k = (uint32_t)lane / g, sidx = (uint32_t)lane - slot_k * g;
     const uint32_t first = SPREAD ? g : rp.first; // samples in a pixel's sums when its fate is first decided
-    // Visits are taken from a counter (in the order of the frame's tiles) when the call has work memory: a wave that drew
-    // cheap tiles goes on to the next ones instead of ending while others still have theirs before them.
-    const bool draw = RTMI_DRAW_VISITS && !SPREAD && wk_hdr != nullptr; // (a spread visit is one sample long: the counter would be its cost)
-    __shared__ uint32_t next_visit;
+    // DRAW: visits are taken from a counter (in the order of the frame's tiles) instead of strided over: a wave that drew
+    // cheap tiles goes on to the next ones instead of ending while others still have theirs before them.  (A kernel of its
+    // own: the same loop with a run-time switch cost the tree kernel 20 % at one sample per pixel, where nothing is drawn.)
+    static_assert(!(DRAW && SPREAD), "a spread visit is one sample long: the counter would be its cost");
     for (uint32_t visit = blockIdx.x;; ) {
-        if (draw) {
-            if (lane == 0) next_visit = atomicAdd(&wk_hdr[WK_VISIT_HEAD], 1u);
-            __syncthreads();
-            visit = next_visit;
-            __syncthreads();
+        if constexpr (DRAW) {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&wk_hdr[WK_VISIT_HEAD], 1u);
+            visit = __builtin_amdgcn_readfirstlane(v); // (every lane is here: lane 0 is the first)
         }
         if (visit >= rp.n_visits) break;
         const unsigned long long q = (unsigned long long)visit * rp.ppw + slot_k;
@@ -323,7 +322,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
             out[o + 0] = (float)(sum.x * inv); out[o + 1] = (float)(sum.y * inv); out[o + 2] = (float)(sum.z * inv);
             keep_state<R>(state, (size_t)ly * cam.hsize + x, sum, sos, cnt);
         }
-        if (!draw) visit += gridDim.x;
+        if constexpr (!DRAW) visit += gridDim.x;
     }
     flush_stats(st, stats);
 }
@@ -795,11 +794,17 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
     DPixelState<RTMI_REAL> *state = (DPixelState<RTMI_REAL> *)state_;
     const bool spread = rp.group > 1;
     const bool photon = sc.n_photons != 0; // (kernels of their own, tree kind, one lane per pixel: the host chooses tree = true, no spread)
-    if (photon) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
-    else if (tree && spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
-    else if (tree) hipLaunchKernelGGL((render_kernel<RTMI_REAL, true, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
-    else if (spread) hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, true>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
-    else hipLaunchKernelGGL((render_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state);
+    const bool draw = RTMI_DRAW_VISITS && !spread && wk.hdr != nullptr && grid_resample > 0; // (an open-ended call: its visits are long and uneven)
+#define RTMI_LAUNCH_RENDER(...) hipLaunchKernelGGL((render_kernel<RTMI_REAL, __VA_ARGS__>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state)
+    if (photon && draw) RTMI_LAUNCH_RENDER(true, false, true, true);
+    else if (photon) RTMI_LAUNCH_RENDER(true, false, true, false);
+    else if (tree && spread) RTMI_LAUNCH_RENDER(true, true, false, false);
+    else if (tree && draw) RTMI_LAUNCH_RENDER(true, false, false, true);
+    else if (tree) RTMI_LAUNCH_RENDER(true, false, false, false);
+    else if (spread) RTMI_LAUNCH_RENDER(false, true, false, false);
+    else if (draw) RTMI_LAUNCH_RENDER(false, false, false, true);
+    else RTMI_LAUNCH_RENDER(false, false, false, false);
+#undef RTMI_LAUNCH_RENDER
     if (between) (void)hipEventRecord(between, st); // (rtmi_render_device_timed)
     if (!wk.hdr || grid_resample <= 0) return;
     for (int l = 0; l <= RTMI_SPEC_PASSES + 1; ++l) {
