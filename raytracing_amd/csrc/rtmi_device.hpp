@@ -1577,6 +1577,7 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
     R hd[RTMI_MAX_NEAREST];
     uint32_t hn[RTMI_MAX_NEAREST];
     int cnt = 0;
+    R top = (R)0; // hd[0] while cnt > 0, in a register: it is looked at for every photon visited
     uint32_t stk[PHOTON_STACK];
     int sp = 0;
     const R pc[3] = {p.x, p.y, p.z};
@@ -1595,14 +1596,14 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
             const uint32_t near = d < (R)0 ? left : left + 1u, far = d < (R)0 ? left + 1u : left;
             if (sp + 2 > PHOTON_STACK) { st.c[RTMI_STAT_OVERFLOW] = 1; self = true; } // (never: the tree is balanced)
             else if (stage == 0u) { stk[sp++] = (node << 2) | 1u; stk[sp++] = near << 2; }
-            else if ((d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < hd[0])) { stk[sp++] = (node << 2) | 2u; stk[sp++] = far << 2; }
+            else if ((d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < top)) { stk[sp++] = (node << 2) | 2u; stk[sp++] = far << 2; }
             else self = true;
         }
         if (self) {
             const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
             const R d2 = dx * dx + dy * dy + dz * dz;
             ++visited;
-            if (cnt < k || d2 < hd[0]) {
+            if (cnt < k || d2 < top) {
                 if (cnt == k) { // BinaryHeap::pop: the last entry to the root, then down
                     --cnt;
                     hd[0] = hd[cnt]; hn[0] = hn[cnt];
@@ -1627,10 +1628,11 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
                     const uint32_t tn = hn[q]; hn[q] = hn[i]; hn[i] = tn;
                     i = q;
                 }
+                top = hd[0];
             }
         }
     }
-    const R square_radius = cnt ? hd[0] : (R)1; // (unwrap_or(1.0), photon_map.rs:318)
+    const R square_radius = cnt ? top : (R)1; // (unwrap_or(1.0), photon_map.rs:318)
     V3<R> total = mk<R>(0, 0, 0);
     for (int i = 0; i < cnt; ++i) {
         const DPhoton &ph = sc.photons[min(hn[i], n - 1u)];
