@@ -369,6 +369,20 @@ struct Stats {
 // -DRTMI_CYCLES=1 or 2 (diagnostic builds, tools/cycles.py): where a wave's time goes, summed per wave into the counters
 // aabb_tests, leaf_tests, node_visits and flops INSTEAD of what those normally count.  1: the tree walk and its CSG parts;
 // 2: the three kinds of intersection query (closest hit, shadow, containers).
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 3 // 3: camera ray + Philox, prepare_computations + material + pattern, lighting
+#define CYC3_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CYC3_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
+#else
+#define CYC3_BEGIN(v)
+#define CYC3_END(st, i, v)
+#endif
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 4 // 4: the spawn logic after a hit (weights, schlick, directions, pending stack), popping a pending ray, the sample loop's own work
+#define CYC4_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CYC4_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
+#else
+#define CYC4_BEGIN(v)
+#define CYC4_END(st, i, v)
+#endif
 #if defined(RTMI_CYCLES) && RTMI_CYCLES == 1
 #define CYC_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
 #define CYC_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
@@ -1672,6 +1686,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
         if (h.leaf != NONE) {
             Comps<R> c;
             uint32_t kind, material;
+            CYC3_BEGIN(c_prep);
             prepare<R, TREE>(sc, ray, h, c, kind, material);
             const DMaterial<R> m = load_material<R, TREE>(sc, material);
             V3<R> over_point = c.point + c.normalv * EPS;
@@ -1695,6 +1710,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                     st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u);
                 }
             }
+            CYC3_END(st, 1, c_prep);
             V3<R> surface = mk<R>(0, 0, 0);
             if constexpr (PHOTON) {
                 if (sc.n_photons) surface = photon_estimate(sc, c.point, c.normalv, surface_color, st); // materials.rs:376-384
@@ -1712,7 +1728,9 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                 if (!staged) in = incoming_at(sc.lights[li], over_point, rng);
                 bool in_shadow = is_shadowed<R, TREE>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
                 st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
+                CYC3_BEGIN(c_light);
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
+                CYC3_END(st, 2, c_light);
             }
             surface = mk<R>(min_(max_(surface.x, (R)0), (R)1), min_(max_(surface.y, (R)0), (R)1), min_(max_(surface.z, (R)0), (R)1)); // :399
             acc = acc + (surface + surface_color * m.emissive) * weight;
@@ -1721,6 +1739,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
             bool do_refl = !(m.reflective == (R)0) && remaining > 0;   // materials.rs:297
             bool do_refr = !(m.transparency == (R)0) && remaining > 0; // materials.rs:316
             if (do_refr || want_n) collect_n1n2<R, TREE>(sc, ray, origin_leaf, origin_side, h, c, st);
+            CYC4_BEGIN(c_spawn);
             if (first) {
                 if (first_hit) *first_hit = h;
                 if (first_comps) *first_comps = c;
@@ -1764,16 +1783,19 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                 weight = w_refr; remaining -= 1; origin_leaf = h.leaf; origin_side = c.side_plus ? 0u : SIDE_PLUS; cls = RTMI_STAT_REFRACTION;
                 spawned = true;
             }
+            CYC4_END(st, 0, c_spawn);
         } else if (first && first_hit) {
             *first_hit = h;
         }
         first = false;
         if (!spawned) {
             if (pend.empty()) break;
+            CYC4_BEGIN(c_pop);
             const Pending<R> e = pend.pop(lds_pend);
             ray.o = e.o; ray.d = e.d; weight = e.weight;
             remaining = e.remaining; origin_leaf = e.origin_leaf; origin_side = e.origin_side;
             cls = RTMI_STAT_REFRACTION;
+            CYC4_END(st, 1, c_pop);
         }
     }
     return acc;

@@ -106,7 +106,9 @@ __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<
     rng_begin(rng, (uint32_t)(py * cam.hsize + px), s);
     st.c[RTMI_STAT_SAMPLES]++;
     st.flops += camera_flops(cam);
+    CYC3_BEGIN(c_cam);
     Ray<R> ray = camera_ray<R>(cam, px, py, s != 0, rng);
+    CYC3_END(st, 0, c_cam);
     return color_at<R, TREE, PHOTON>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
 }
 
@@ -266,6 +268,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
         while (go) { // wave-uniform until the pixels' sums hold `first` samples
             V3<R> c = mk<R>(0, 0, 0);
             if (!SPREAD || valid) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
+            CYC4_BEGIN(c_book);
             // camera.rs:277-278: BOTH sums start from the first sample itself - the sum of squares from c, not from c * c -
             // and only the later samples enter it squared (camera.rs:286,297)
             if (grouped) { // the owner adds its group's samples up in sample order, like the reference's loop
@@ -315,6 +318,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) rende
                 }
             }
             go = more;
+            CYC4_END(st, 2, c_book);
         }
         if (owner && !queued) {
             R inv = (R)1 / (R)cnt;

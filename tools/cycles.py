@@ -10,6 +10,10 @@ from raytracing_amd import abi, scenes
 name = sys.argv[1]
 stages = "stages" in sys.argv
 if stages: sys.argv.remove("stages")
+spawn = "spawn" in sys.argv  # a -DRTMI_CYCLES=4 build
+if spawn: sys.argv.remove("spawn")
+shade = "shade" in sys.argv  # a -DRTMI_CYCLES=3 build: camera ray + Philox, prepare_computations + material + pattern, lighting()
+if shade: sys.argv.remove("shade")
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 for det in (True, False):
     world, cam = scenes.BASELINE_SCENES[name](w, h, deterministic=det)
@@ -17,6 +21,16 @@ for det in (True, False):
     img, st = abi.render_host(sc, cam, abi.make_opts())
     sc.close()
     tot = float(st["flops"])
+    if spawn:
+        a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
+        print("%s %s: %.2f ms | of the kernels' wave cycles: spawn logic after a hit %.1f %%, popping a pending ray %.1f %%, the sample loop's own work (sums, stop test, policy, queues) %.1f %%" % (
+            name, "1spp" if det else "shipped", st["kernel_ms"], 100 * a, 100 * b, 100 * c))
+        continue
+    if shade:
+        a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
+        print("%s %s: %.2f ms | of the kernels' wave cycles: camera ray + Philox %.1f %%, prepare_computations + material + pattern %.1f %%, lighting() %.1f %%" % (
+            name, "1spp" if det else "shipped", st["kernel_ms"], 100 * a, 100 * b, 100 * c))
+        continue
     if stages:
         a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
         rays = st["primary"] + st["reflection"] + st["refraction"] + st["shadow"]
