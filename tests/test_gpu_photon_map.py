@@ -50,6 +50,32 @@ def test_random_rays_against_the_oracle(direct, n_nearest, radius):
         assert ref.max() > 1e-3  # (the map is all the light there is: the comparison is of the estimate)
 
 
+@pytest.mark.parametrize("n_photons", [1, 2, 3, 5, 8, 64])
+def test_small_and_degenerate_maps(n_photons):
+    """Maps of a handful of photons (every shape of the left-balanced tree's last level), more neighbours asked for than there
+    are photons, and coincident photons (both sides order equal coordinates by index): f64 colours equal the oracle's."""
+    world, cam = scenes.photon_room(64, 32, direct=False)
+    rng = np.random.default_rng(n_photons)
+    pos = np.column_stack([rng.uniform(-2, 2, n_photons), np.zeros(n_photons), rng.uniform(-2, 3, n_photons)])
+    if n_photons >= 5:
+        pos[1] = pos[0]; pos[3] = pos[0]  # coincident
+    ph = orc.make_photons(pos, np.tile([0.0, 1.0, 0.0], (n_photons, 1)), np.full((n_photons, 3), 0.5))
+    photon_cases.attach(world, ph, 16, 0.0)
+    flat = world.flatten()
+    sc = abi.Scene(world)
+    n = 300
+    o = rng.uniform(-3, 3, (n, 3)) + np.array([0, 3.0, -2.0])
+    d = np.column_stack([rng.uniform(-2, 2, n), np.zeros(n), rng.uniform(-2, 3, n)]) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c64, _ = abi.trace_rays(sc, o, d, opts=abi.make_opts(precision=1))
+    c32, _ = abi.trace_rays(sc, o, d, opts=abi.make_opts(precision=0))
+    sc.close()
+    ref = np.array([orc.color_at(flat, o[i], d[i], world.max_reflection_depth)[1] for i in range(n)])
+    assert ref.max() > 0
+    assert np.abs(c64 - ref).max() < 1e-9
+    assert (np.abs(c32 - ref).max(axis=1) < 2e-3 * np.maximum(1.0, np.abs(ref).max(axis=1))).mean() >= 0.99
+
+
 @pytest.mark.parametrize("precision", [1, 0], ids=["f64", "f32"])
 @pytest.mark.parametrize("direct", [True, False], ids=["with-lights", "map-only"])
 def test_frame_one_sample(precision, direct):
