@@ -336,6 +336,44 @@ int rtmi_camera_rays(const rtmi_camera *camera, const rtmi_render_opts *opts, in
                      const int32_t *px, const int32_t *py, const int32_t *sample,
                      double *origins_out, double *directions_out);
 
+/* Replaces the tracing half of `World::compute_photon_map` (world.rs:186-201): n_emit times
+ * `World::emit_photon` (world.rs:211-215: a light chosen by `Light::power`, its `emit_photon`,
+ * lights.rs:104-111,169-176,252-261,371-380,462-473) and `World::trace_photon` (world.rs:217-273) with
+ * `Phong::photon_hit` (materials.rs:414-464: store where the diffuse reflectance is above EPSILON, then
+ * Russian roulette between absorb / `scatter` / `reflect` / `refract`, photon_map.rs:144-172), and
+ * `scale_power(1 / n_emit)` (world.rs:200).  The photons come back as the reference collects them: in
+ * order of emission, each photon's hits in order of its bounces (rayon's indexed collect keeps that order),
+ * ready for rtmi_scene_desc.photons (the balancing half, PhotonMap::from_vec, happens there).
+ * The reference draws from thread_rng; here the draws of photon i come from the Philox stream
+ * (seed with its high word xor "PHOT", counter (i, 0, draw)), so a call is reproducible.  Where the
+ * reference has no answer this library ends the photon: a path longer than max_bounces (the reference
+ * loops for ever in a closed lossless scene; counted in n_truncated), a refraction beyond the critical
+ * angle (photon_map.rs:165 takes the root of a negative number).  A material whose absorption
+ * probability is negative (materials.rs:443-444 panics) gives RTMI_ERR_INVALID naming the leaf, and so
+ * does a world whose lights all have power 0 (world.rs:212 panics).  `Material::transform_photon`
+ * (materials.rs:30-36) is the default (None) for every material this library holds.
+ * HOST buffers.  `out` receives the first min(n_stored, capacity) photons; n_stored is always the whole
+ * count, so (NULL, 0) asks for the size.  A scene's own photon map, if it has one, plays no part.     */
+typedef struct rtmi_photon_opts {
+    uint64_t seed;
+    int64_t n_emit;          /* n_photons of compute_photon_map, 1 .. 2^31 - 1                          */
+    int32_t precision;       /* RTMI_PRECISION_F32 / _F64                                              */
+    int32_t enable_direct;   /* World::enable_direct_photon_map  (world.rs:64: false)                  */
+    int32_t enable_diffuse;  /* World::enable_diffuse_photon_map (world.rs:65: true)                   */
+    int32_t enable_caustic;  /* World::enable_caustic_photon_map (world.rs:66: true)                   */
+    int32_t max_bounces;     /* 0 = RTMI_PHOTON_BOUNCES                                                */
+    int32_t reserved;
+} rtmi_photon_opts;
+#define RTMI_PHOTON_BOUNCES 256
+typedef struct rtmi_photon_result {
+    int64_t n_stored;    /* photons the whole call stores                                              */
+    int64_t n_rays;      /* World::intersect calls (world.rs:234)                                      */
+    int64_t n_truncated; /* paths ended by max_bounces                                                 */
+    double kernel_ms;    /* device time of the tracing kernel                                          */
+} rtmi_photon_result;
+int rtmi_trace_photons(const rtmi_scene *scene, const rtmi_photon_opts *opts, rtmi_photon *out,
+                       int64_t capacity, rtmi_photon_result *result);
+
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char *rtmi_last_error(void);
 

@@ -944,8 +944,8 @@ struct World {
     std::vector<Light> lights;
     std::vector<SceneItem> objects;
     uint32_t max_reflection_depth = 10; // world.rs:61
-    // world.rs:18-22.  The map is GIVEN here (set_photon_map): tracing photons (compute_photon_map, world.rs:186-273) is not
-    // part of this library; its gather in Phong::shade_hit (materials.rs:376-384) is.
+    // world.rs:18-22.  The map is either GIVEN (set_photon_map) or traced on the device (compute_photon_map, below); its
+    // gather in Phong::shade_hit (materials.rs:376-384) runs in the render kernels.
     std::vector<rtmi_photon> photon_map;
     size_t n_nearest = 0;
     double max_search_radius = 0.0; // (<= 0: unlimited)
@@ -962,6 +962,10 @@ struct World {
         for (const auto &q : photons) photon_map.push_back(q.p);
         n_nearest = nearest; max_search_radius = max_radius;
     }
+
+    // World::compute_photon_map (world.rs:186-209): rtmi_trace_photons on a device copy of this world, then the map is
+    // kept for the renders that follow.  `seed` has no counterpart (the reference draws from thread_rng).
+    inline rtmi_photon_result compute_photon_map(size_t n_photons, size_t nearest, double max_radius, uint64_t seed = 0x5EED, int precision = RTMI_PRECISION_F32);
 
     static World empty() { return World(); }
     static World default_world() { // world.rs:25-53
@@ -1005,6 +1009,23 @@ struct DeviceScene {
     DeviceScene &operator=(const DeviceScene &) = delete;
     ~DeviceScene() { if (handle) rtmi_scene_destroy(handle); }
 };
+
+inline rtmi_photon_result World::compute_photon_map(size_t n_photons, size_t nearest, double max_radius, uint64_t seed, int precision) {
+    drop_photon_map(); // "Save some memory", world.rs:192 (and the device copy below carries no map)
+    DeviceScene scene(*this);
+    rtmi_photon_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.seed = seed; o.n_emit = (int64_t)n_photons; o.precision = precision;
+    o.enable_direct = direct_photon_map_enabled; o.enable_diffuse = diffuse_photon_map_enabled; o.enable_caustic = caustic_photon_map_enabled;
+    rtmi_photon_result res;
+    if (rtmi_trace_photons(scene.handle, &o, nullptr, 0, &res) != RTMI_OK) throw std::runtime_error(std::string("rtmi_trace_photons: ") + rtmi_last_error());
+    std::vector<rtmi_photon> found((size_t)res.n_stored);
+    if (res.n_stored > 0 && rtmi_trace_photons(scene.handle, &o, found.data(), res.n_stored, &res) != RTMI_OK)
+        throw std::runtime_error(std::string("rtmi_trace_photons: ") + rtmi_last_error());
+    photon_map.swap(found);
+    n_nearest = nearest; max_search_radius = max_radius;
+    return res;
+}
 
 // ---------------------------------------------------------------------------------------------
 // camera.rs

@@ -1229,3 +1229,180 @@ int orc_render(const rtmi_scene_desc *scene, const rtmi_camera *cam, const rtmi_
 void orc_to_u8(const double *rgb, int64_t n, uint8_t *out) {
     for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)round(clip1(rgb[i], 0.0, 1.0) * 255.0);
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* World::compute_photon_map's tracing half (world.rs:186-273)                                  */
+/* ------------------------------------------------------------------------------------------- */
+enum { PK_DIRECT = 0, PK_CAUSTIC = 1, PK_DIFFUSE = 2 }; /* PhotonKind, photon_map.rs:185-190 */
+
+/* UnitSphere by inverse CDF (two draws), the map incoming_at uses for SphereLight */
+static v3 unit_sphere(rng_t *g) {
+    double u1 = rng_next(g), u2 = rng_next(g);
+    double z = 1.0 - 2.0 * u1, phi = 2.0 * ORC_PI * u2;
+    double rr = sqrt(fmax(0.0, 1.0 - z * z));
+    return V(rr * cos(phi), rr * sin(phi), z);
+}
+
+/* CosineDistribution::sample (cosine_distribution.rs:16-28); the loop is cut after 16 rounds (direction itself) */
+static v3 cosine_sample(v3 dir, rng_t *g) {
+    for (int k = 0; k < 16; ++k) {
+        v3 v = vadd(dir, unit_sphere(g));
+        double l = vdot(v, v);
+        if (l > EPS) return vmul(v, 1.0 / sqrt(l));
+    }
+    return dir;
+}
+void orc_cosine_sample(const double *dir, uint64_t seed, uint32_t index, double *out) {
+    rng_t g = {seed, index, 0, 0};
+    to3(cosine_sample(from3(dir), &g), out);
+}
+
+/* TravellingPhoton::reflect / refract (photon_map.rs:153-172): the new direction */
+void orc_photon_reflect(const double *dir, const double *normv, double *out) { to3(vreflect(from3(dir), from3(normv)), out); }
+int orc_photon_refract(const double *dir, const double *normv, double n1, double n2, double *out) {
+    v3 d = from3(dir), n = from3(normv);
+    double n_ratio = n1 / n2;
+    double cos_i = -vdot(d, n);
+    double sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
+    if (sin2_t > 1.0) return 0; /* (the reference takes sqrt of a negative number here: no answer) */
+    double cos_t = sqrt(1.0 - sin2_t);
+    to3(vadd(vmul(n, n_ratio * cos_i - cos_t), vmul(d, n_ratio)), out);
+    return 1;
+}
+
+/* Light::power (lights.rs:68-70,100-102,165-167,248-250,298-300,367-369,458-460) */
+static double light_power(const rtmi_light *l) {
+    if (l->kind == RTMI_LIGHT_AMBIENT) return 0.0;
+    return (l->intensity[0] + l->intensity[1] + l->intensity[2]) / 3.0;
+}
+
+/* Light::emit_photon (lights.rs:104-111,169-176,252-261,371-380,462-473) */
+static void light_emit(const rtmi_light *l, rng_t *g, ray_t *ray, v3 *power) {
+    v3 pos = from3(l->position), I = from3(l->intensity);
+    ray->o = pos; *power = I;
+    switch (l->kind) {
+    case RTMI_LIGHT_POINT: ray->d = unit_sphere(g); break;
+    case RTMI_LIGHT_REALISTIC_POINT: ray->d = unit_sphere(g); *power = vmul(vmul(I, 2.0), 1.0 / ORC_PI); break;
+    case RTMI_LIGHT_BEAM: { /* two StandardNormal draws: Box-Muller on two uniforms */
+        double u1 = rng_next(g), u2 = rng_next(g);
+        double r = sqrt(-2.0 * log(1.0 - u1)), phi = 2.0 * ORC_PI * u2;
+        double u = r * cos(phi), v = r * sin(phi);
+        ray->o = vadd(vadd(pos, vmul(from3(l->up), u)), vmul(from3(l->right), v));
+        ray->d = from3(l->direction);
+        *power = vmul(vmul(I, 2.0), 1.0 / ORC_PI);
+        break;
+    }
+    case RTMI_LIGHT_SPHERE: {
+        v3 p = unit_sphere(g);
+        ray->d = cosine_sample(p, g);
+        ray->o = vadd(pos, vmul(p, l->radius));
+        break;
+    }
+    case RTMI_LIGHT_DISC: { /* UnitDisc by inverse CDF as in incoming_at */
+        double u1 = rng_next(g), u2 = rng_next(g);
+        double rr = sqrt(u1), phi = 2.0 * ORC_PI * u2;
+        ray->o = vadd(vadd(pos, vmul(from3(l->width), rr * cos(phi))), vmul(from3(l->height), rr * sin(phi)));
+        ray->d = cosine_sample(from3(l->normal), g);
+        *power = vmul(vmul(vmul(I, 0.25), 2.0), 1.0 / ORC_PI);
+        break;
+    }
+    default: ray->d = V(0, 0, 0); *power = V(0, 0, 0);
+    }
+}
+
+/* rand 0.7.3 WeightedIndex: the first index whose cumulative weight exceeds x = u * total; a rounded-up x falls to the
+ * last index with a weight */
+static int weighted_index(const double *w, int n, double u) {
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += w[i];
+    double x = u * total, cum = 0.0;
+    int last = -1;
+    for (int i = 0; i < n; ++i) {
+        if (w[i] > 0.0) last = i;
+        cum += w[i];
+        if (x < cum) return i;
+    }
+    return last;
+}
+
+/* returns the number of photons the call stores (out holds the first min(that, capacity)); -1: no light with power;
+ * -2 - leaf: Phong::photon_hit's assert on the absorption probability fails at that leaf (materials.rs:443-445) */
+int64_t orc_trace_photons(const rtmi_scene_desc *sc, const rtmi_photon_opts *o, rtmi_photon *out, int64_t capacity, int64_t *n_rays,
+                          int64_t *n_truncated) {
+    ctx_t cx; ctx_init(&cx, sc, 0);
+    int64_t stored = 0, rays = 0, truncated = 0;
+    const int max_bounces = o->max_bounces > 0 ? o->max_bounces : RTMI_PHOTON_BOUNCES;
+    const int direct_only = o->enable_direct && !o->enable_caustic && !o->enable_diffuse; /* world.rs:130-134 */
+    double *lw = (double *)malloc((size_t)(sc->n_lights + 1) * sizeof(double));
+    double total_power = 0.0;
+    for (int i = 0; i < sc->n_lights; ++i) { lw[i] = light_power(&sc->lights[i]); total_power += lw[i]; }
+    if (!(total_power > 0.0)) { free(lw); ctx_done(&cx); return -1; }
+    const float inv_n = (float)(1.0 / (double)o->n_emit);
+    int64_t result = 0;
+    for (int64_t idx = 0; idx < o->n_emit && result >= 0; ++idx) {
+        rng_t g = {o->seed ^ ((uint64_t)0x50484F54u << 32), (uint32_t)idx, 0, 0};
+        ray_t ray; v3 power;
+        int li = weighted_index(lw, sc->n_lights, rng_next(&g)); /* world.rs:211-215 */
+        light_emit(&sc->lights[li], &g, &ray, &power);
+        int kind = PK_DIRECT;
+        for (int bounce = 0;; ++bounce) {
+            if (bounce >= max_bounces) { truncated++; break; }
+            if (power.x + power.y + power.z < EPS) break; /* world.rs:224-226 */
+            if (kind != PK_DIRECT && direct_only) break;  /* world.rs:228-232 */
+            xlist xs; xl_init(&xs);
+            world_intersect(&cx, ray, 0, &xs);
+            rays++;
+            int h = hit_index(&xs);
+            if (h < 0) { xl_free(&xs); break; }
+            comps_t c = prepare_computations(&cx, &xs.xs[h], ray, &xs);
+            xl_free(&xs);
+            const rtmi_material *m = &sc->materials[sc->leaves[c.leaf].material];
+            /* Phong::photon_hit (materials.rs:414-464) */
+            v3 dr = vmul(surface_color_at(&cx, &c), m->diffuse);
+            double spec = fmax(m->specular, m->reflective), trans = m->transparency;
+            double pd_avg = (dr.x + dr.y + dr.z) / 3.0;
+            int store = pd_avg > EPS;
+            if (!o->enable_diffuse) pd_avg = 0.0;
+            if (m->reflective > 0.0 && m->transparency > 0.0) {
+                double r = schlick(c.eyev, c.normalv, c.n1, c.n2);
+                spec *= r; trans *= 1.0 - r;
+            }
+            double w[4] = {1.0 - pd_avg - spec - trans, pd_avg, spec, trans};
+            if (!(w[0] >= 0.0)) { result = -2 - c.leaf; break; }
+            int choice = weighted_index(w, 4, rng_next(&g));
+            if (store && ((kind == PK_DIRECT && o->enable_direct) || (kind == PK_DIFFUSE && o->enable_diffuse) ||
+                          (kind == PK_CAUSTIC && o->enable_caustic))) { /* world.rs:256-265 */
+                if (stored < capacity && out) {
+                    rtmi_photon *p = &out[stored];
+                    memset(p, 0, sizeof *p);
+                    double pw[3] = {power.x, power.y, power.z};
+                    p->position[0] = (float)c.point.x; p->position[1] = (float)c.point.y; p->position[2] = (float)c.point.z;
+                    p->direction[0] = (float)-ray.d.x; p->direction[1] = (float)-ray.d.y; p->direction[2] = (float)-ray.d.z;
+                    orc_compress_color(pw, &p->power_scale, p->power_rgb); /* StoredPhoton::new, photon_map.rs:23-30 */
+                    p->power_scale *= inv_n;                               /* scale_power, photon_map.rs:61-64 */
+                }
+                stored++;
+            }
+            if (choice == 0) break;
+            if (choice == 1) { /* TravellingPhoton::scatter (photon_map.rs:144-151) */
+                double avg = (dr.x + dr.y + dr.z) / 3.0;
+                ray.o = c.over_point; ray.d = cosine_sample(c.normalv, &g);
+                power = vmul(vhad(power, dr), 1.0 / avg);
+                kind = PK_DIFFUSE;
+            } else if (choice == 2) { /* reflect (photon_map.rs:153-159) */
+                ray.d = vreflect(ray.d, c.normalv); ray.o = c.over_point;
+                if (kind == PK_DIRECT) kind = PK_CAUSTIC;
+            } else { /* refract (photon_map.rs:161-172) */
+                double nd[3], dd[3] = {ray.d.x, ray.d.y, ray.d.z}, nn[3] = {c.normalv.x, c.normalv.y, c.normalv.z};
+                if (!orc_photon_refract(dd, nn, c.n1, c.n2, nd)) break;
+                ray.o = c.under_point; ray.d = from3(nd);
+                if (kind == PK_DIRECT) kind = PK_CAUSTIC;
+            }
+        }
+    }
+    free(lw);
+    ctx_done(&cx);
+    if (n_rays) *n_rays = rays;
+    if (n_truncated) *n_truncated = truncated;
+    return result < 0 ? result : stored;
+}

@@ -101,6 +101,16 @@ void orc_photon_balance(const rtmi_photon *photons, int64_t n, const double *lo,
 int orc_find_nearest(const rtmi_photon *photons, int64_t n, double max_search_radius, int n_neighbors, const double *p,
                      int64_t *found, double *max_sq);
 
+/* World::compute_photon_map's tracing half (world.rs:186-273; materials.rs:414-464; photon_map.rs:144-172; the lights'
+ * emit_photon): the number of photons stored (out: the first min(that, capacity), in the reference's order), -1 when no
+ * light has power (world.rs:212 panics), -2 - leaf when a material's absorption probability is negative
+ * (materials.rs:443-445 panics).  Draws: the Philox stream rtmi_trace_photons documents. */
+int64_t orc_trace_photons(const rtmi_scene_desc *scene, const rtmi_photon_opts *opts, rtmi_photon *out, int64_t capacity,
+                          int64_t *n_rays, int64_t *n_truncated);
+void orc_photon_reflect(const double *dir, const double *normv, double *out);
+int orc_photon_refract(const double *dir, const double *normv, double n1, double n2, double *out);
+void orc_cosine_sample(const double *dir, uint64_t seed, uint32_t index, double *out);
+
 void orc_to_u8(const double *rgb, int64_t n_values, uint8_t *out);
 
 #ifdef __cplusplus

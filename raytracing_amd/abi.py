@@ -14,7 +14,7 @@ STAT_NAMES = ("primary", "reflection", "refraction", "shadow", "samples", "leaf_
 # every symbol include/rtmi.h declares
 SYMBOLS = (
     "rtmi_rank_rows", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render", "rtmi_render_device", "rtmi_render_device_noalloc", "rtmi_render_device_timed", "rtmi_render_multi", "rtmi_progressive_begin", "rtmi_progressive_pass", "rtmi_progressive_end",
-    "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
+    "rtmi_tonemap_u8_device", "rtmi_trace_rays", "rtmi_trace_photons", "rtmi_camera_rays", "rtmi_last_error", "rtmi_describe",
 )
 
 
@@ -36,6 +36,15 @@ class HitRecord(C.Structure):
     _fields_ = [("hit", C.c_int32), ("leaf", C.c_int32), ("inside", C.c_int32), ("reserved", C.c_int32), ("t", C.c_double),
                 ("point", C.c_double * 3), ("normal", C.c_double * 3), ("n1", C.c_double), ("n2", C.c_double),
                 ("shadowed", C.c_double)]
+
+
+class PhotonOpts(C.Structure):  # rtmi_photon_opts
+    _fields_ = [("seed", C.c_uint64), ("n_emit", C.c_int64), ("precision", C.c_int32), ("enable_direct", C.c_int32), ("enable_diffuse", C.c_int32),
+                ("enable_caustic", C.c_int32), ("max_bounces", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PhotonResult(C.Structure):  # rtmi_photon_result
+    _fields_ = [("n_stored", C.c_int64), ("n_rays", C.c_int64), ("n_truncated", C.c_int64), ("kernel_ms", C.c_double)]
 
 
 _lib = None
@@ -67,6 +76,7 @@ def lib():
                                       C.c_void_p]
         L.rtmi_camera_rays.argtypes = [C.c_void_p, C.POINTER(RenderOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
+        L.rtmi_trace_photons.argtypes = [C.c_void_p, C.POINTER(PhotonOpts), C.c_void_p, C.c_int64, C.POINTER(PhotonResult)]
         L.rtmi_describe.argtypes = [C.c_char_p, C.c_int32]
         _lib = L
     return _lib
@@ -210,6 +220,31 @@ def trace_rays(scene, origins, directions, remaining=None, opts=None, want_hits=
     check(lib().rtmi_trace_rays(scene.handle, C.byref(opts), n, o.ctypes.data, d.ctypes.data, rem.ctypes.data if rem is not None else None,
                                 rgb.ctypes.data, C.cast(recs, C.c_void_p) if recs is not None else None), "rtmi_trace_rays")
     return rgb, recs
+
+
+def photon_dtype():
+    import numpy as np
+    return np.dtype([("position", np.float32, 3), ("direction", np.float32, 3), ("power_scale", np.float32), ("power_rgb", np.uint8, 3),
+                     ("reserved", np.uint8)])  # rtmi_photon, 32 bytes
+
+
+def make_photon_opts(n_emit, seed=0x5EED, precision=0, direct=False, diffuse=True, caustic=True, max_bounces=0):
+    """The flags default to World::new's (world.rs:64-66)."""
+    return PhotonOpts(seed, n_emit, precision, int(direct), int(diffuse), int(caustic), max_bounces, 0)
+
+
+def trace_photons(scene, opts, capacity=None):
+    """The tracing half of World::compute_photon_map (rtmi_trace_photons): returns (photons as a structured array in the
+    reference's order, result dict).  capacity None: ask for the count first, then fetch all of them."""
+    import numpy as np
+    res = PhotonResult()
+    if capacity is None:
+        check(lib().rtmi_trace_photons(scene.handle, C.byref(opts), None, 0, C.byref(res)), "rtmi_trace_photons")
+        capacity = int(res.n_stored)
+    out = np.zeros(max(capacity, 1), dtype=photon_dtype())
+    check(lib().rtmi_trace_photons(scene.handle, C.byref(opts), out.ctypes.data if capacity else None, capacity, C.byref(res)), "rtmi_trace_photons")
+    n = min(int(res.n_stored), capacity)
+    return out[:n], {"n_stored": int(res.n_stored), "n_rays": int(res.n_rays), "n_truncated": int(res.n_truncated), "kernel_ms": float(res.kernel_ms)}
 
 
 def camera_rays(camera, px, py, sample=None, opts=None):

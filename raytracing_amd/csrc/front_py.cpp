@@ -262,6 +262,14 @@ PYBIND11_MODULE(_front, m) {
         .def("photon_map_enabled", &World::photon_map_enabled).def("drop_photon_map", &World::drop_photon_map)
         .def("set_photon_map", &World::set_photon_map, py::arg("photons"), py::arg("n_nearest"), py::arg("max_search_radius") = 0.0)
         .def("n_photons", [](const World &w) { return w.photon_map.size(); })
+        .def("compute_photon_map", [](World &w, size_t n_photons, size_t nearest, double max_radius, uint64_t seed, int precision) {
+            const rtmi_photon_result r = w.compute_photon_map(n_photons, nearest, max_radius, seed, precision);
+            py::dict d;
+            d["n_stored"] = r.n_stored; d["n_rays"] = r.n_rays; d["n_truncated"] = r.n_truncated; d["kernel_ms"] = r.kernel_ms;
+            return d;
+        }, py::arg("n_photons"), py::arg("n_nearest"), py::arg("max_search_radius"), py::arg("seed") = 0x5EED, py::arg("precision") = 0)
+        // (the stored photons as one array of 32-byte records, rtmi_photon)
+        .def("photon_bytes", [](const World &w) { return py::bytes((const char *)w.photon_map.data(), w.photon_map.size() * sizeof(rtmi_photon)); })
         // (positions float32[n,3], directions float32[n,3], power_scale float32[n], power_rgb uint8[n,3]: the stored photons as arrays)
         .def("set_photon_arrays", [](World &w, py::array_t<float, py::array::c_style | py::array::forcecast> pos,
                                      py::array_t<float, py::array::c_style | py::array::forcecast> dir,

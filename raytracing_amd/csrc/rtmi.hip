@@ -225,6 +225,7 @@ struct rtmi_scene {
     DScene<float> h32;
     DScene<double> h64;
     int num_cu = 256;
+    double emit_power = 0.0; // sum of Light::power over World::lights (world.rs:212)
 };
 
 static bool is_csg_kind(int k) { return k >= RTMI_NODE_CSG_UNION && k <= RTMI_NODE_CSG_DIFFERENCE; }
@@ -1115,6 +1116,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     s->device = dev;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) s->num_cu = prop.multiProcessorCount;
+    for (int32_t i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].kind != RTMI_LIGHT_AMBIENT) s->emit_power += (desc->lights[i].intensity[0] + desc->lights[i].intensity[1] + desc->lights[i].intensity[2]) / 3.0;
     std::vector<uint32_t> tri_of_leaf;
     std::vector<DWTri> wtris = world_space_triangles(desc, L, tri_of_leaf);
     std::vector<DBvh2> bvh2;
@@ -1627,6 +1630,85 @@ extern "C" int rtmi_trace_rays(const rtmi_scene *scene, const rtmi_render_opts *
     TRY_OR_CLEAN(hipDeviceSynchronize());
     if (rgb_out) TRY_OR_CLEAN(hipMemcpy(rgb_out, d_rgb, b3, hipMemcpyDeviceToHost));
     if (hits_out) TRY_OR_CLEAN(hipMemcpy(hits_out, d_rec, (size_t)n * sizeof(rtmi_hit_record), hipMemcpyDeviceToHost));
+    cleanup();
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_trace_photons(const rtmi_scene *scene, const rtmi_photon_opts *opts, rtmi_photon *out, int64_t capacity, rtmi_photon_result *result) {
+    if (!scene || !opts || !result || capacity < 0 || (capacity > 0 && !out)) return fail(RTMI_ERR_INVALID, "bad trace_photons arguments");
+    memset(result, 0, sizeof *result);
+    if (opts->n_emit < 1 || opts->n_emit > 0x7FFFFFFFll) return fail(RTMI_ERR_INVALID, "n_emit = " + std::to_string(opts->n_emit) + " is outside [1, 2^31 - 1]");
+    if (opts->max_bounces < 0 || opts->max_bounces > 65535) return fail(RTMI_ERR_INVALID, "max_bounces = " + std::to_string(opts->max_bounces) + " is outside [0, 65535]");
+    if (opts->precision != RTMI_PRECISION_F32 && opts->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
+    if (!(scene->emit_power > 0.0)) return fail(RTMI_ERR_INVALID, "no light of the scene has power to emit photons (world.rs:212)");
+    int dev = -1, rc = ensure_device(&dev);
+    if (rc != RTMI_OK) return rc;
+    if (dev != scene->device)
+        return fail(RTMI_ERR_DEVICE, "the scene lives on device " + std::to_string(scene->device) + " but the current HIP device is " + std::to_string(dev));
+    DPhotonTrace pt;
+    pt.seed_lo = (uint32_t)opts->seed; pt.seed_hi = (uint32_t)(opts->seed >> 32) ^ 0x50484F54u;
+    pt.n_emit = (uint32_t)opts->n_emit;
+    pt.max_bounces = (uint32_t)(opts->max_bounces > 0 ? opts->max_bounces : RTMI_PHOTON_BOUNCES);
+    pt.enable_direct = opts->enable_direct != 0; pt.enable_diffuse = opts->enable_diffuse != 0; pt.enable_caustic = opts->enable_caustic != 0;
+    pt.direct_only = pt.enable_direct && !pt.enable_caustic && !pt.enable_diffuse;
+    pt.inv_n = (float)(1.0 / (double)opts->n_emit);
+    const bool f64 = opts->precision == RTMI_PRECISION_F64;
+    // lanes: enough waves to fill the GPU a few times over, never more lanes than photons
+    const long long waves_wanted = (long long)scene->num_cu * 16;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(waves_wanted, (opts->n_emit + 63) / 64));
+    rtmi_photon *d_out = nullptr;
+    unsigned long long *d_keys = nullptr, *d_cnt = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_out); (void)hipFree(d_keys); (void)hipFree(d_cnt);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        d_out = nullptr; d_keys = nullptr; d_cnt = nullptr; e0 = e1 = nullptr;
+    };
+    TRY_OR_CLEAN(hipMalloc((void **)&d_cnt, PT_COUNTERS * sizeof(unsigned long long)));
+    TRY_OR_CLEAN(hipEventCreate(&e0));
+    TRY_OR_CLEAN(hipEventCreate(&e1));
+    unsigned long long cnt[PT_COUNTERS] = {0, 0, 0, 0};
+    // The device appends in the order its lanes get there; the keys (photon, bounce) put the hits back into the order of
+    // world.rs:195-201.  A first run with room for 2 hits per photon (and at least the caller's capacity); if the scene
+    // stores more, the count it reports sizes a second run - same seed, same photons.
+    uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)opts->n_emit * 2 + 1024, 1024));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        pt.cap = (uint32_t)cap;
+        TRY_OR_CLEAN(hipMalloc((void **)&d_out, cap * sizeof(rtmi_photon)));
+        TRY_OR_CLEAN(hipMalloc((void **)&d_keys, cap * sizeof(unsigned long long)));
+        TRY_OR_CLEAN(hipMemset(d_cnt, 0, PT_COUNTERS * sizeof(unsigned long long)));
+        TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+        if (f64) launch_photon_trace_kernel<double>(grid, nullptr, scene->h64, pt, d_out, d_keys, d_cnt);
+        else launch_photon_trace_kernel<float>(grid, nullptr, scene->h32, pt, d_out, d_keys, d_cnt);
+        TRY_OR_CLEAN(hipGetLastError());
+        TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+        TRY_OR_CLEAN(hipDeviceSynchronize());
+        TRY_OR_CLEAN(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+        if (cnt[PT_STORED] <= cap) break;
+        if (attempt == 1 || cnt[PT_STORED] > 0xFFFFFFF0ull) { cleanup(); return fail(RTMI_ERR_UNSUPPORTED, "the call stores " + std::to_string(cnt[PT_STORED]) + " photons: more than one call holds"); }
+        (void)hipFree(d_out); (void)hipFree(d_keys); d_out = nullptr; d_keys = nullptr;
+        cap = cnt[PT_STORED];
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (cnt[PT_BAD_LEAF]) {
+        cleanup();
+        return fail(RTMI_ERR_INVALID, "the material of leaf " + std::to_string(cnt[PT_BAD_LEAF] - 1) + " reflects and transmits more than it receives: diffuse * colour + max(specular, reflective) + transparency > 1 (materials.rs:443-445)");
+    }
+    const size_t n = (size_t)cnt[PT_STORED];
+    result->n_stored = (int64_t)n; result->n_rays = (int64_t)cnt[PT_RAYS]; result->n_truncated = (int64_t)cnt[PT_TRUNCATED]; result->kernel_ms = ms;
+    if (capacity > 0 && n > 0) {
+        std::vector<rtmi_photon> ph(n);
+        std::vector<unsigned long long> keys(n);
+        TRY_OR_CLEAN(hipMemcpy(ph.data(), d_out, n * sizeof(rtmi_photon), hipMemcpyDeviceToHost));
+        TRY_OR_CLEAN(hipMemcpy(keys.data(), d_keys, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; }); // (a key is unique: one store per bounce)
+        const size_t m = std::min<size_t>(n, (size_t)capacity);
+        for (size_t i = 0; i < m; ++i) out[i] = ph[order[i]];
+    }
     cleanup();
     return RTMI_OK;
 }

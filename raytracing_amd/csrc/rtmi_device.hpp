@@ -1801,6 +1801,209 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
     return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// World::compute_photon_map's tracing half (world.rs:186-273) - rtmi_trace_photons
+// ---------------------------------------------------------------------------------------------
+struct DPhotonTrace {
+    uint32_t seed_lo, seed_hi; // (the photon stream's key: the caller's seed with "PHOT" xored into the high word)
+    uint32_t n_emit, max_bounces;
+    uint32_t enable_direct, enable_diffuse, enable_caustic, direct_only; // world.rs:64-66,130-134
+    float inv_n;  // scale_power(1 / n_photons), world.rs:200
+    uint32_t cap; // photons `out` and `keys` hold
+};
+enum { PT_STORED = 0, PT_RAYS = 1, PT_TRUNCATED = 2, PT_BAD_LEAF = 3, PT_COUNTERS = 4 };
+enum { PK_DIRECT = 0, PK_CAUSTIC = 1, PK_DIFFUSE = 2 }; // PhotonKind, photon_map.rs:185-190
+
+__device__ __forceinline__ float log_(float x) { return logf(x); }
+__device__ __forceinline__ double log_(double x) { return log(x); }
+__device__ __forceinline__ float third_(float x) { return x * (1.0f / 3.0f); }
+__device__ __forceinline__ double third_(double x) { return x / 3.0; } // Color::sum() / 3.0 as the reference rounds it
+
+// UnitSphere by inverse CDF (two draws), the map incoming_at uses for SphereLight
+template <typename R> __device__ __forceinline__ V3<R> unit_sphere(Rng &rng) {
+    R u1 = rng_next<R>(rng), u2 = rng_next<R>(rng);
+    R z = (R)1 - (R)2 * u1, s, c;
+    sincos2pi(u2, s, c);
+    R rr = sqrt_(max_((R)0, (R)1 - z * z));
+    return mk<R>(rr * c, rr * s, z);
+}
+// CosineDistribution::sample (cosine_distribution.rs:16-28); the loop is cut after 16 rounds (the direction itself)
+template <typename R> __device__ __forceinline__ V3<R> cosine_sample(V3<R> dir, Rng &rng) {
+    for (int k = 0; k < 16; ++k) {
+        V3<R> v = dir + unit_sphere<R>(rng);
+        R l = dot(v, v);
+        if (l > (R)RTMI_EPSILON) return v * rsqrt_(l);
+    }
+    return dir;
+}
+// Light::power (lights.rs:68-70 and each light's `power`): the ambient light has none
+template <typename R> __device__ __forceinline__ R light_power(const DLight<R> &l) {
+    return l.kind == RTMI_LIGHT_AMBIENT ? (R)0 : third_(l.intensity[0] + l.intensity[1] + l.intensity[2]);
+}
+// Light::emit_photon (lights.rs:104-111,169-176,252-261,371-380,462-473)
+template <typename R> __device__ __forceinline__ void light_emit(const DLight<R> &l, Rng &rng, Ray<R> &ray, V3<R> &power) {
+    const R TWO_OVER_PI = (R)(2.0 / 3.14159265358979323846);
+    V3<R> pos = ld3(l.pos);
+    ray.o = pos; power = ld3(l.intensity); ray.d = mk<R>(0, 0, 0);
+    switch (l.kind) {
+    case RTMI_LIGHT_POINT: ray.d = unit_sphere<R>(rng); break;
+    case RTMI_LIGHT_REALISTIC_POINT: ray.d = unit_sphere<R>(rng); power = power * TWO_OVER_PI; break;
+    case RTMI_LIGHT_BEAM: { // two StandardNormal draws: Box-Muller on two uniforms
+        R u1 = rng_next<R>(rng), u2 = rng_next<R>(rng), s, c;
+        R r = sqrt_((R)-2 * log_((R)1 - u1));
+        sincos2pi(u2, s, c);
+        ray.o = pos + ld3(l.up) * (r * c) + ld3(l.right) * (r * s);
+        ray.d = ld3(l.dir);
+        power = power * TWO_OVER_PI;
+        break;
+    }
+    case RTMI_LIGHT_SPHERE: {
+        V3<R> p = unit_sphere<R>(rng);
+        ray.d = cosine_sample(p, rng);
+        ray.o = pos + p * l.radius;
+        break;
+    }
+    case RTMI_LIGHT_DISC: {
+        R u1 = rng_next<R>(rng), u2 = rng_next<R>(rng);
+        R rr = sqrt_(u1), s, c;
+        sincos2pi(u2, s, c);
+        ray.o = pos + ld3(l.width) * (rr * c) + ld3(l.height) * (rr * s);
+        ray.d = cosine_sample(ld3(l.normal), rng);
+        power = power * ((R)0.25 * TWO_OVER_PI);
+        break;
+    }
+    default: power = mk<R>(0, 0, 0);
+    }
+}
+// StoredPhoton::new + scale_power (photon_map.rs:23-39,61-64): f32 position and direction, the power as an f32 scale
+// and three bytes (f32 arithmetic whatever R is; a NaN quotient, 0 / 0, becomes 0 as Rust's f32::max makes it)
+template <typename R> __device__ __forceinline__ void store_photon(rtmi_photon *p, V3<R> point, V3<R> travel, V3<R> power, float inv_n) {
+    p->position[0] = (float)point.x; p->position[1] = (float)point.y; p->position[2] = (float)point.z;
+    p->direction[0] = (float)-travel.x; p->direction[1] = (float)-travel.y; p->direction[2] = (float)-travel.z;
+    const float x = (float)max_(max_(power.x, power.y), power.z);
+    const float ch[3] = {(float)power.x, (float)power.y, (float)power.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = 255.0f * ch[k] / x;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        p->power_rgb[k] = (uint8_t)v;
+    }
+    p->reserved = 0;
+    p->power_scale = x * inv_n;
+}
+
+// One lane traces the photons first, first + stride, ... : emission and bounces are ONE loop, so a lane whose photon
+// has ended emits its next one while the wave's other lanes are still bouncing theirs.  Every turn of the loop either
+// ends a photon or spends one of its max_bounces, and the photon index only grows: every lane leaves the loop.
+template <typename R>
+__device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhotonTrace &pt, uint32_t first, uint32_t stride, rtmi_photon *out,
+                                              unsigned long long *keys, unsigned long long *counters, Stats &st) {
+    const R EPS = (R)RTMI_EPSILON;
+    unsigned long long rays = 0, truncated = 0;
+    uint32_t next = first, idx = 0, bounce = 0, origin_leaf = NONE, origin_side = 0;
+    int kind = PK_DIRECT;
+    bool alive = false;
+    Ray<R> ray = {mk<R>(0, 0, 0), mk<R>(0, 0, 1)};
+    V3<R> power = mk<R>(0, 0, 0);
+    Rng rng;
+    rng.k0 = pt.seed_lo; rng.k1 = pt.seed_hi;
+    R total_power = 0;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) total_power += light_power(sc.lights[i]);
+    for (;;) {
+        if (!alive) {
+            if (next >= pt.n_emit) break;
+            idx = next;
+            next = (pt.n_emit - next > stride) ? next + stride : pt.n_emit; // (no wrap-around near 2^32)
+            rng_begin(rng, idx, 0);
+            // World::emit_photon (world.rs:211-215): WeightedIndex over the lights' power
+            const R x = rng_next<R>(rng) * total_power;
+            R cum = 0;
+            uint32_t li = 0;
+            for (uint32_t i = 0; i < sc.n_lights; ++i) {
+                const R w = light_power(sc.lights[i]);
+                if (w > (R)0) li = i; // (a rounded-up x falls to the last light with power)
+                cum += w;
+                if (x < cum) break;
+            }
+            light_emit(sc.lights[li], rng, ray, power);
+            kind = PK_DIRECT; bounce = 0; origin_leaf = NONE; origin_side = 0;
+            alive = true;
+        }
+        // World::trace_photon (world.rs:217-273), one turn of its loop
+        if (bounce >= pt.max_bounces) { truncated++; alive = false; continue; }
+        bounce++;
+        if (power.x + power.y + power.z < EPS) { alive = false; continue; }      // world.rs:224-226
+        if (kind != PK_DIRECT && pt.direct_only) { alive = false; continue; }     // world.rs:228-232
+        Hit<R> h = {Lim<R>::inf(), NONE, 0};
+        Open<R> unused;
+        traverse<R, MODE_CLOSEST, true>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
+        rays++;
+        if (h.leaf == NONE) { alive = false; continue; }
+        Comps<R> c;
+        uint32_t lkind, material;
+        prepare<R, true>(sc, ray, h, c, lkind, material);
+        const DMaterial<R> m = sc.materials[material];
+        V3<R> surface_color = ld3(m.color);
+        if (m.pattern >= 0) surface_color = pattern_at(sc.patterns[m.pattern], xf_point(sc.leaves[h.leaf].inv, c.point));
+        // Phong::photon_hit (materials.rs:414-464)
+        const V3<R> dr = surface_color * m.diffuse;
+        R spec = max_(m.specular, m.reflective), trans = m.transparency;
+        const R dr_avg = third_(dr.x + dr.y + dr.z);
+        R pd_avg = dr_avg;
+        const bool store = pd_avg > EPS;
+        if (!pt.enable_diffuse) pd_avg = 0;
+        if (m.transparency > (R)0) collect_n1n2<R, true>(sc, ray, origin_leaf, origin_side, h, c, st); // (n1, n2 are read by schlick and refract only)
+        if (m.reflective > (R)0 && m.transparency > (R)0) {
+            const R r = schlick(c.eyev, c.normalv, c.n1, c.n2);
+            spec *= r; trans *= (R)1 - r;
+        }
+        const R p_absorb = (R)1 - pd_avg - spec - trans;
+        if (!(p_absorb >= (R)0)) { // materials.rs:443-445 panics: the call fails and names the leaf
+            counters[PT_BAD_LEAF] = (unsigned long long)sc.leaf_orig[h.leaf] + 1ull;
+            alive = false;
+            continue;
+        }
+        // WeightedIndex over [absorb, diffuse, specular, transmit]: the first whose cumulative weight exceeds x
+        const R c0 = p_absorb, c1 = c0 + pd_avg, c2 = c1 + spec, c3 = c2 + trans;
+        const R x = rng_next<R>(rng) * c3;
+        int choice = x < c0 ? 0 : x < c1 ? 1 : x < c2 ? 2 : 3;
+        if (choice == 3 && !(trans > (R)0)) choice = spec > (R)0 ? 2 : pd_avg > (R)0 ? 1 : 0; // (x rounded up to the total)
+        if (store && ((kind == PK_DIRECT && pt.enable_direct) || (kind == PK_DIFFUSE && pt.enable_diffuse) || (kind == PK_CAUSTIC && pt.enable_caustic))) {
+            const unsigned long long slot = atomicAdd(&counters[PT_STORED], 1ull); // world.rs:256-265
+            if (slot < (unsigned long long)pt.cap) {
+                store_photon(&out[slot], c.point, ray.d, power, pt.inv_n);
+                keys[slot] = ((unsigned long long)idx << 16) | (unsigned long long)(bounce - 1u);
+            }
+        }
+        const uint32_t side_over = c.side_plus ? SIDE_PLUS : 0u, side_under = c.side_plus ? 0u : SIDE_PLUS;
+        if (choice == 0) { alive = false; continue; }
+        if (choice == 1) { // TravellingPhoton::scatter (photon_map.rs:144-151)
+            ray.o = c.point + c.normalv * EPS;
+            ray.d = cosine_sample(c.normalv, rng);
+            power = had(power, dr) * rcp_(dr_avg);
+            kind = PK_DIFFUSE; origin_side = side_over;
+        } else if (choice == 2) { // reflect (photon_map.rs:153-159)
+            ray.d = ray.d - c.normalv * ((R)2 * dot(ray.d, c.normalv));
+            ray.o = c.point + c.normalv * EPS;
+            if (kind == PK_DIRECT) kind = PK_CAUSTIC;
+            origin_side = side_over;
+        } else { // refract (photon_map.rs:161-172)
+            const R n_ratio = div_(c.n1, c.n2);
+            const R cos_i = -dot(ray.d, c.normalv);
+            const R sin2_t = n_ratio * n_ratio * ((R)1 - cos_i * cos_i);
+            if (sin2_t > (R)1) { alive = false; continue; } // (the reference takes the root of a negative number: no answer)
+            const R cos_t = sqrt_((R)1 - sin2_t);
+            ray.d = c.normalv * (n_ratio * cos_i - cos_t) + ray.d * n_ratio;
+            ray.o = c.point - c.normalv * EPS;
+            if (kind == PK_DIRECT) kind = PK_CAUSTIC;
+            origin_side = side_under;
+        }
+        origin_leaf = h.leaf;
+    }
+    if (rays) atomicAdd(&counters[PT_RAYS], rays);
+    if (truncated) atomicAdd(&counters[PT_TRUNCATED], truncated);
+}
+
 // Camera::ray_for_pixel (camera.rs:120-153)
 template <typename R> __device__ __forceinline__ uint32_t camera_flops(const DCamera<R> &cam) {
     return F_CAMERA + (cam.aperture_size == (R)0 ? 0u : F_CAMERA_LENS);

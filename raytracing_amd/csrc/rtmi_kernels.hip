@@ -770,6 +770,20 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
     }
 }
 
+// World::compute_photon_map's tracing half (rtmi_trace_photons): lane l of the grid traces photons l, l + lanes, ...
+template <typename R>
+__global__ void __launch_bounds__(64) photon_trace_kernel(DScene<R> sc, DPhotonTrace pt, rtmi_photon *out, unsigned long long *keys,
+                                                          unsigned long long *counters) {
+    Stats st;
+#pragma unroll
+    for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
+    st.flops = 0;
+#ifdef RTMI_CYCLES
+    st.cyc[0] = st.cyc[1] = st.cyc[2] = st.cyc[3] = 0;
+#endif
+    trace_photons<R>(sc, pt, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, out, keys, counters, st);
+}
+
 // Camera::ray_for_pixel for a batch of (px, py, sample) (rtmi_camera_rays)
 template <typename R>
 __global__ void camera_rays_kernel(DCamera<double> cam, uint32_t seed_lo, uint32_t seed_hi, long long n, const int *px, const int *py,
@@ -836,6 +850,11 @@ void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint3
                                     const double *origins, const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
     if (sc.n_photons) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
     else hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
+}
+template <>
+void launch_photon_trace_kernel<RTMI_REAL>(int grid, hipStream_t st, const DScene<RTMI_REAL> &sc, const DPhotonTrace &pt, rtmi_photon *out,
+                                           unsigned long long *keys, unsigned long long *counters) {
+    hipLaunchKernelGGL(photon_trace_kernel<RTMI_REAL>, dim3(grid), dim3(64), 0, st, sc, pt, out, keys, counters);
 }
 template <>
 void launch_camera_rays_kernel<RTMI_REAL>(int grid, const DCamera<double> &cam, uint32_t seed_lo, uint32_t seed_hi, long long n,

@@ -256,6 +256,32 @@ def photon_room_with_map(h=300, v=150, deterministic=False, n_photons=2_000_000,
     return w, cam
 
 
+def photon_box(h=600, v=600, deterministic=False, direct=True):
+    """rust/examples/photon-map.rs:15-78: a closed room of six planes (white, one red and one green wall) under a disc light
+    of 1000 at the ceiling, a rotated box and a glass ball; SE 1e-2, at least 100 samples.  Its materials are the ones
+    Phong::photon_hit accepts (diffuse 0.5, no specular term: materials.rs:443-445), so this is the scene
+    World::compute_photon_map (rtmi_trace_photons) is exercised and measured on."""
+    w = rt.World.empty()
+    w.add_light(rt.DiscLight(rt.point(0, 8, 4), rt.vector(0, -1, 0), 0.5, rt.color(1000, 1000, 1000)))
+
+    def matt(r, g, b):
+        return rt.Phong.default().with_rgb(r, g, b).with_emissive(0.0).with_diffuse(0.5).with_specular(0.0).with_shininess(100.0)
+    white, red, green = matt(1, 1, 1), matt(1, 0.3, 0.3), matt(0.3, 1, 0.3)
+    w.add_item(rt.plane().with_material(white))
+    w.add_item(rt.plane().with_material(white).with_transform(rt.translation(0, 10, 0)))
+    w.add_item(rt.plane().with_material(white).with_transform(rt.translation(0, 0, 5) * rt.rotation_x(PI / 2.0)))
+    w.add_item(rt.plane().with_material(red).with_transform(rt.translation(-5, 0, 0) * rt.rotation_z(PI / 2.0)))
+    w.add_item(rt.plane().with_material(green).with_transform(rt.translation(5, 0, 0) * rt.rotation_z(PI / 2.0)))
+    w.add_item(rt.plane().with_material(white).with_transform(rt.translation(0, 0, -5) * rt.rotation_x(PI / 2.0)))
+    w.add_item(rt.cube().with_material(white).with_transform(rt.translation(-2, 2, 2) * rt.rotation_y(0.8) * rt.scaling(1, 2, 1)))
+    w.add_item(rt.sphere().with_material(
+        rt.Phong.default().with_rgb(1.0, 1.0, 1.0).with_diffuse(0.0).with_specular(0.0).with_shininess(250.0).with_transparency(0.9)
+        .with_refractive_index(1.5).with_reflective(0.0)).with_transform(rt.translation(2, 1.5, 2) * rt.scaling(1.5, 1.5, 1.5)))
+    w.enable_direct_illumination(direct)
+    w.finalize_scene()
+    return w, _camera(h, v, (0, 5, -4.9), (0, 5, 0), se=1e-2, min_samples=100, deterministic=deterministic, fov=PI / 2.0)
+
+
 def soft_shadow(h=900, v=450, deterministic=False):
     """rust/examples/soft_shadow.rs:12-59 — BASELINE config 4 (area light)."""
     w = rt.World.empty()

@@ -216,3 +216,46 @@ def find_nearest(photons, n_neighbors, p, max_search_radius=0.0):
     pp = v3(p)
     k = lib().orc_find_nearest(photons.ctypes.data, len(photons), float(max_search_radius), int(n_neighbors), pp.ctypes.data, found.ctypes.data, C.byref(msq))
     return found[:k].tolist(), float(msq.value)
+
+
+def trace_photons(flat, opts, capacity=None):
+    """orc_trace_photons: (photons in the reference's order, {"n_stored", "n_rays", "n_truncated"}); a negative n_stored is the
+    oracle's error code (-1: no light with power; -2 - leaf: absorption probability below zero at that leaf)."""
+    L = lib()
+    L.orc_trace_photons.restype = C.c_int64
+    L.orc_trace_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rays, trunc = C.c_int64(0), C.c_int64(0)
+    if capacity is None:
+        capacity = max(int(L.orc_trace_photons(flat.desc_address(), C.addressof(opts), None, 0, C.byref(rays), C.byref(trunc))), 0)
+    out = np.zeros(max(capacity, 1), dtype=PHOTON_DTYPE)
+    n = int(L.orc_trace_photons(flat.desc_address(), C.addressof(opts), out.ctypes.data, capacity, C.byref(rays), C.byref(trunc)))
+    return out[:max(min(n, capacity), 0)], {"n_stored": n, "n_rays": rays.value, "n_truncated": trunc.value}
+
+
+def photon_reflect(direction, normal):
+    out = np.zeros(3)
+    L = lib()
+    L.orc_photon_reflect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_photon_reflect.restype = None
+    d, n = v3(direction), v3(normal)
+    L.orc_photon_reflect(d.ctypes.data, n.ctypes.data, out.ctypes.data)
+    return out
+
+
+def photon_refract(direction, normal, n1, n2):
+    out = np.zeros(3)
+    L = lib()
+    L.orc_photon_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    d, n = v3(direction), v3(normal)
+    ok = L.orc_photon_refract(d.ctypes.data, n.ctypes.data, n1, n2, out.ctypes.data)
+    return out if ok else None
+
+
+def cosine_sample(direction, seed, index):
+    out = np.zeros(3)
+    L = lib()
+    L.orc_cosine_sample.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.orc_cosine_sample.restype = None
+    d = v3(direction)
+    L.orc_cosine_sample(d.ctypes.data, seed, index, out.ctypes.data)
+    return out
