@@ -353,7 +353,8 @@ int rtmi_camera_rays(const rtmi_camera *camera, const rtmi_render_opts *opts, in
  * does a world whose lights all have power 0 (world.rs:212 panics).  `Material::transform_photon`
  * (materials.rs:30-36) is the default (None) for every material this library holds.
  * HOST buffers.  `out` receives the first min(n_stored, capacity) photons; n_stored is always the whole
- * count, so (NULL, 0) asks for the size.  A scene's own photon map, if it has one, plays no part.     */
+ * count, so (NULL, 0) asks for the size (and runs the counting pass only).  A scene's own photon map,
+ * if it has one, plays no part.                                                                       */
 typedef struct rtmi_photon_opts {
     uint64_t seed;
     int64_t n_emit;          /* n_photons of compute_photon_map, 1 .. 2^31 - 1                          */
@@ -369,7 +370,7 @@ typedef struct rtmi_photon_result {
     int64_t n_stored;    /* photons the whole call stores                                              */
     int64_t n_rays;      /* World::intersect calls (world.rs:234)                                      */
     int64_t n_truncated; /* paths ended by max_bounces                                                 */
-    double kernel_ms;    /* device time of the tracing kernel                                          */
+    double kernel_ms;    /* device time of the call's kernels (counting pass, scan, storing pass)     */
 } rtmi_photon_result;
 int rtmi_trace_photons(const rtmi_scene *scene, const rtmi_photon_opts *opts, rtmi_photon *out,
                        int64_t capacity, rtmi_photon_result *result);

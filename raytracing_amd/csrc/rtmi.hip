@@ -12,6 +12,8 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 using namespace rtmi_dev;
@@ -66,6 +68,75 @@ __global__ void deinterleave_kernel(const float *__restrict__ src, float *__rest
         dst[((tile * nranks + rank) * tile_rows + within) * row_values + col] = src[i];
     }
 }
+
+// Exclusive scan of the per-photon hit counts (rtmi_trace_photons): blocks of 1024 counts (256 lanes x 4), their sums
+// scanned by one block, then the offsets.  `sums` holds n_blocks + 1 values; the last one is the total.
+#ifndef RTMI_HOST_EMUL
+constexpr uint32_t SCAN_BLOCK = 1024;
+template <bool APPLY>
+__global__ void __launch_bounds__(256) scan_counts_kernel(const uint32_t *__restrict__ counts, uint32_t n, unsigned long long *__restrict__ sums,
+                                                          uint32_t *__restrict__ offsets) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x;
+    const unsigned long long at = (unsigned long long)blockIdx.x * SCAN_BLOCK + t * 4u;
+    uint32_t v[4], own = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = at + k < n ? counts[at + k] : 0u; own += v[k]; }
+    part[t] = own;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) { // inclusive scan of the lanes' sums (a block's counts stay far below 2^32)
+        const uint32_t x = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    if constexpr (!APPLY) {
+        if (t == 255) sums[blockIdx.x] = part[255];
+    } else {
+        unsigned long long run = sums[blockIdx.x] + (part[t] - own);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (at + k < n) offsets[at + k] = (uint32_t)run; // (the host refuses totals beyond 32 bits before anything reads these)
+            run += v[k];
+        }
+    }
+}
+__global__ void __launch_bounds__(1024) scan_sums_kernel(unsigned long long *sums, uint32_t n_blocks) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t t = threadIdx.x;
+    unsigned long long carry = 0;
+    for (uint32_t first = 0; first < n_blocks; first += 1024) { // (uniform trip count: every lane meets every barrier)
+        const uint32_t i = first + t;
+        const unsigned long long own = i < n_blocks ? sums[i] : 0ull;
+        part[t] = own;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const unsigned long long x = t >= off ? part[t - off] : 0ull;
+            __syncthreads();
+            part[t] += x;
+            __syncthreads();
+        }
+        if (i < n_blocks) sums[i] = carry + part[t] - own;
+        carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0) sums[n_blocks] = carry;
+}
+static void scan_counts(const uint32_t *counts, uint32_t n, unsigned long long *sums, uint32_t *offsets, hipStream_t st) {
+    const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(scan_counts_kernel<false>, dim3(nb), dim3(256), 0, st, counts, n, sums, offsets);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nb);
+    hipLaunchKernelGGL(scan_counts_kernel<true>, dim3(nb), dim3(256), 0, st, counts, n, sums, offsets);
+}
+#else
+constexpr uint32_t SCAN_BLOCK = 1024;
+static void scan_counts(const uint32_t *counts, uint32_t n, unsigned long long *sums, uint32_t *offsets, hipStream_t) { // (host emulation: "device" memory is host memory)
+    const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    unsigned long long run = 0;
+    for (uint32_t i = 0; i < n; ++i) { offsets[i] = (uint32_t)run; run += counts[i]; }
+    sums[nb] = run;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // host: scene layout
@@ -814,44 +885,73 @@ static long long kd_left_children(long long n) { // compute_number_of_left_child
     const long long full = 1ll << depth, last = n - (full - 1);
     return last <= full / 2 ? (full - 2) / 2 + last : (full - 2) / 2 + full / 2;
 }
+// The recursion of PhotonMap::balance works on disjoint ranges of the photons and writes disjoint nodes: the top of the
+// tree is split on the calling thread until there are enough subtrees, which host threads (at most 16, RTMI_HOST_THREADS)
+// then take one at a time.  Keys sit next to their indices, so the selection reads 8-byte pairs instead of chasing photons.
 static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) {
     std::vector<DPhoton> out((size_t)n);
-    std::vector<uint32_t> idx((size_t)n);
-    for (long long i = 0; i < n; ++i) idx[(size_t)i] = (uint32_t)i;
+    struct KI { float key; uint32_t idx; };
+    std::vector<KI> ki((size_t)n);
+    for (long long i = 0; i < n; ++i) ki[(size_t)i].idx = (uint32_t)i;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}; // compute_extent, photon_map.rs:415-421
     for (long long i = 0; i < n; ++i)
         for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], (double)ph[i].position[a]); hi[a] = std::fmax(hi[a], (double)ph[i].position[a]); }
     struct Job { long long first, count, node; double lo[3], hi[3]; };
-    std::vector<Job> todo;
-    Job root = {0, n, 0, {lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
-    todo.push_back(root);
     auto put = [&](long long node, uint32_t i, uint32_t flag) {
         DPhoton &q = out[(size_t)node];
         for (int k = 0; k < 3; ++k) { q.pos[k] = ph[i].position[k]; q.dir[k] = ph[i].direction[k]; }
         q.scale = ph[i].power_scale;
         q.rgbf = (uint32_t)ph[i].power_rgb[0] | ((uint32_t)ph[i].power_rgb[1] << 8) | ((uint32_t)ph[i].power_rgb[2] << 16) | (flag << 24);
     };
-    while (!todo.empty()) {
-        const Job j = todo.back();
-        todo.pop_back();
-        if (j.count == 0 || j.node >= n) continue;
-        if (j.count == 1) { put(j.node, idx[(size_t)j.first], KD_LEAF); continue; }
+    // one node: the split photon into its place, the two sides appended to `todo`
+    auto step = [&](const Job &j, std::vector<Job> &todo) {
+        if (j.count == 0 || j.node >= n) return;
+        if (j.count == 1) { put(j.node, ki[(size_t)j.first].idx, KD_LEAF); return; }
         const long long n_left = kd_left_children(j.count);
         const double sx = j.hi[0] - j.lo[0], sy = j.hi[1] - j.lo[1], sz = j.hi[2] - j.lo[2];
         const int axis = (sx >= sy && sx >= sz) ? 0 : ((sy >= sx && sy >= sz) ? 1 : 2); // photon_map.rs:270-294
+        KI *base = ki.data() + j.first;
+        for (long long i = 0; i < j.count; ++i) base[i].key = ph[base[i].idx].position[axis];
         // partition_by_key(n_left, ..): the n_left smallest keys in front, the next one at n_left (equal keys: by index -
         // the reference leaves them to its partial sort)
-        std::nth_element(idx.begin() + j.first, idx.begin() + j.first + n_left, idx.begin() + j.first + j.count, [&](uint32_t a, uint32_t b) {
-            const float x = ph[a].position[axis], y = ph[b].position[axis];
-            return x < y || (x == y && a < b);
-        });
-        const uint32_t m = idx[(size_t)(j.first + n_left)];
+        std::nth_element(base, base + n_left, base + j.count, [](const KI &a, const KI &b) { return a.key < b.key || (a.key == b.key && a.idx < b.idx); });
+        const uint32_t m = base[n_left].idx;
         const double median = (double)ph[m].position[axis];
         put(j.node, m, (uint32_t)(KD_SPLIT_X + axis));
         Job l = j, r = j;
         l.count = n_left; l.node = 2 * (j.node + 1) - 1; l.hi[axis] = median;            // Aabb::split_*, aabb.rs:105-127
         r.first = j.first + n_left + 1; r.count = j.count - n_left - 1; r.node = 2 * (j.node + 1); r.lo[axis] = median;
         todo.push_back(l); todo.push_back(r);
+    };
+    int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("RTMI_HOST_THREADS")) n_threads = std::max(1, std::min(64, atoi(e)));
+    if (n < 200000) n_threads = 1;
+    std::vector<Job> level, next;
+    Job root = {0, n, 0, {lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+    level.push_back(root);
+    // breadth first until every thread has a few subtrees to take (one thread: the loop below does it all)
+    while (n_threads > 1 && !level.empty() && level.size() < (size_t)n_threads * 4) {
+        next.clear();
+        for (const Job &j : level) step(j, next);
+        level.swap(next);
+    }
+    auto subtree = [&](const Job &top) {
+        std::vector<Job> todo;
+        todo.push_back(top);
+        while (!todo.empty()) {
+            const Job j = todo.back();
+            todo.pop_back();
+            step(j, todo);
+        }
+    };
+    if (n_threads <= 1) {
+        for (const Job &j : level) subtree(j);
+    } else {
+        std::atomic<size_t> taken{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t)
+            pool.emplace_back([&]() { for (size_t k; (k = taken.fetch_add(1)) < level.size();) subtree(level[k]); });
+        for (auto &th : pool) th.join();
     }
     return out;
 }
@@ -1652,63 +1752,63 @@ extern "C" int rtmi_trace_photons(const rtmi_scene *scene, const rtmi_photon_opt
     pt.enable_direct = opts->enable_direct != 0; pt.enable_diffuse = opts->enable_diffuse != 0; pt.enable_caustic = opts->enable_caustic != 0;
     pt.direct_only = pt.enable_direct && !pt.enable_caustic && !pt.enable_diffuse;
     pt.inv_n = (float)(1.0 / (double)opts->n_emit);
+    pt.cap = 0;
     const bool f64 = opts->precision == RTMI_PRECISION_F64;
     // lanes: enough waves to fill the GPU a few times over, never more lanes than photons
     const long long waves_wanted = (long long)scene->num_cu * 16;
     const int grid = (int)std::max<long long>(1, std::min<long long>(waves_wanted, (opts->n_emit + 63) / 64));
+    const uint32_t n = pt.n_emit, nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     rtmi_photon *d_out = nullptr;
-    unsigned long long *d_keys = nullptr, *d_cnt = nullptr;
+    uint32_t *d_counts = nullptr, *d_offsets = nullptr;
+    unsigned long long *d_sums = nullptr, *d_cnt = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
-        (void)hipFree(d_out); (void)hipFree(d_keys); (void)hipFree(d_cnt);
+        (void)hipFree(d_out); (void)hipFree(d_counts); (void)hipFree(d_offsets); (void)hipFree(d_sums); (void)hipFree(d_cnt);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
-        d_out = nullptr; d_keys = nullptr; d_cnt = nullptr; e0 = e1 = nullptr;
+        d_out = nullptr; d_counts = d_offsets = nullptr; d_sums = d_cnt = nullptr; e0 = e1 = nullptr;
     };
     TRY_OR_CLEAN(hipMalloc((void **)&d_cnt, PT_COUNTERS * sizeof(unsigned long long)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_counts, (size_t)n * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_offsets, (size_t)n * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc((void **)&d_sums, ((size_t)nb + 1) * sizeof(unsigned long long)));
     TRY_OR_CLEAN(hipEventCreate(&e0));
     TRY_OR_CLEAN(hipEventCreate(&e1));
-    unsigned long long cnt[PT_COUNTERS] = {0, 0, 0, 0};
-    // The device appends in the order its lanes get there; the keys (photon, bounce) put the hits back into the order of
-    // world.rs:195-201.  A first run with room for 2 hits per photon (and at least the caller's capacity); if the scene
-    // stores more, the count it reports sizes a second run - same seed, same photons.
-    uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>((uint64_t)opts->n_emit * 2 + 1024, 1024));
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        pt.cap = (uint32_t)cap;
-        TRY_OR_CLEAN(hipMalloc((void **)&d_out, cap * sizeof(rtmi_photon)));
-        TRY_OR_CLEAN(hipMalloc((void **)&d_keys, cap * sizeof(unsigned long long)));
-        TRY_OR_CLEAN(hipMemset(d_cnt, 0, PT_COUNTERS * sizeof(unsigned long long)));
-        TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
-        if (f64) launch_photon_trace_kernel<double>(grid, nullptr, scene->h64, pt, d_out, d_keys, d_cnt);
-        else launch_photon_trace_kernel<float>(grid, nullptr, scene->h32, pt, d_out, d_keys, d_cnt);
-        TRY_OR_CLEAN(hipGetLastError());
-        TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
-        TRY_OR_CLEAN(hipDeviceSynchronize());
-        TRY_OR_CLEAN(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
-        if (cnt[PT_STORED] <= cap) break;
-        if (attempt == 1 || cnt[PT_STORED] > 0xFFFFFFF0ull) { cleanup(); return fail(RTMI_ERR_UNSUPPORTED, "the call stores " + std::to_string(cnt[PT_STORED]) + " photons: more than one call holds"); }
-        (void)hipFree(d_out); (void)hipFree(d_keys); d_out = nullptr; d_keys = nullptr;
-        cap = cnt[PT_STORED];
-    }
-    float ms = 0;
+    TRY_OR_CLEAN(hipMemset(d_cnt, 0, PT_COUNTERS * sizeof(unsigned long long)));
+    // pass 1: every photon's path, counting the hits it keeps; then where each photon's hits go
+    TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+    if (f64) launch_photon_trace_kernel<double>(false, grid, nullptr, scene->h64, pt, nullptr, d_counts, nullptr, d_cnt);
+    else launch_photon_trace_kernel<float>(false, grid, nullptr, scene->h32, pt, nullptr, d_counts, nullptr, d_cnt);
+    TRY_OR_CLEAN(hipGetLastError());
+    scan_counts(d_counts, n, d_sums, d_offsets, nullptr);
+    TRY_OR_CLEAN(hipGetLastError());
+    TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    unsigned long long cnt[PT_COUNTERS] = {0, 0, 0, 0}, total = 0;
+    TRY_OR_CLEAN(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(&total, d_sums + nb, sizeof total, hipMemcpyDeviceToHost));
+    float ms = 0, ms2 = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (cnt[PT_BAD_LEAF]) {
         cleanup();
         return fail(RTMI_ERR_INVALID, "the material of leaf " + std::to_string(cnt[PT_BAD_LEAF] - 1) + " reflects and transmits more than it receives: diffuse * colour + max(specular, reflective) + transparency > 1 (materials.rs:443-445)");
     }
-    const size_t n = (size_t)cnt[PT_STORED];
-    result->n_stored = (int64_t)n; result->n_rays = (int64_t)cnt[PT_RAYS]; result->n_truncated = (int64_t)cnt[PT_TRUNCATED]; result->kernel_ms = ms;
-    if (capacity > 0 && n > 0) {
-        std::vector<rtmi_photon> ph(n);
-        std::vector<unsigned long long> keys(n);
-        TRY_OR_CLEAN(hipMemcpy(ph.data(), d_out, n * sizeof(rtmi_photon), hipMemcpyDeviceToHost));
-        TRY_OR_CLEAN(hipMemcpy(keys.data(), d_keys, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> order(n);
-        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; }); // (a key is unique: one store per bounce)
-        const size_t m = std::min<size_t>(n, (size_t)capacity);
-        for (size_t i = 0; i < m; ++i) out[i] = ph[order[i]];
+    if (total > 0xFFFFFFF0ull) { cleanup(); return fail(RTMI_ERR_UNSUPPORTED, "the call stores " + std::to_string(total) + " photons: more than one call holds (2^32 - 16)"); }
+    result->n_stored = (int64_t)total; result->n_rays = (int64_t)cnt[PT_RAYS]; result->n_truncated = (int64_t)cnt[PT_TRUNCATED];
+    if (capacity > 0 && total > 0) {
+        // pass 2: the same paths again, each hit written to its place
+        pt.cap = (uint32_t)total;
+        TRY_OR_CLEAN(hipMalloc((void **)&d_out, (size_t)total * sizeof(rtmi_photon)));
+        TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+        if (f64) launch_photon_trace_kernel<double>(true, grid, nullptr, scene->h64, pt, d_out, nullptr, d_offsets, d_cnt);
+        else launch_photon_trace_kernel<float>(true, grid, nullptr, scene->h32, pt, d_out, nullptr, d_offsets, d_cnt);
+        TRY_OR_CLEAN(hipGetLastError());
+        TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+        TRY_OR_CLEAN(hipDeviceSynchronize());
+        (void)hipEventElapsedTime(&ms2, e0, e1);
+        TRY_OR_CLEAN(hipMemcpy(out, d_out, (size_t)std::min<unsigned long long>(total, (unsigned long long)capacity) * sizeof(rtmi_photon), hipMemcpyDeviceToHost));
     }
+    result->kernel_ms = (double)ms + (double)ms2;
     cleanup();
     return RTMI_OK;
 }

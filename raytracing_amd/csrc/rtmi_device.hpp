@@ -1809,9 +1809,9 @@ struct DPhotonTrace {
     uint32_t n_emit, max_bounces;
     uint32_t enable_direct, enable_diffuse, enable_caustic, direct_only; // world.rs:64-66,130-134
     float inv_n;  // scale_power(1 / n_photons), world.rs:200
-    uint32_t cap; // photons `out` and `keys` hold
+    uint32_t cap; // photons `out` holds (the storing pass)
 };
-enum { PT_STORED = 0, PT_RAYS = 1, PT_TRUNCATED = 2, PT_BAD_LEAF = 3, PT_COUNTERS = 4 };
+enum { PT_RAYS = 0, PT_TRUNCATED = 1, PT_BAD_LEAF = 2, PT_COUNTERS = 4 };
 enum { PK_DIRECT = 0, PK_CAUSTIC = 1, PK_DIFFUSE = 2 }; // PhotonKind, photon_map.rs:185-190
 
 __device__ __forceinline__ float log_(float x) { return logf(x); }
@@ -1895,12 +1895,16 @@ template <typename R> __device__ __forceinline__ void store_photon(rtmi_photon *
 // One lane traces the photons first, first + stride, ... : emission and bounces are ONE loop, so a lane whose photon
 // has ended emits its next one while the wave's other lanes are still bouncing theirs.  Every turn of the loop either
 // ends a photon or spends one of its max_bounces, and the photon index only grows: every lane leaves the loop.
-template <typename R>
+// The call runs the photons twice (same stream, same paths): STORE false counts the hits photon i keeps into counts[i];
+// after an exclusive scan of the counts, STORE true writes them at offsets[i], i + 1, ... - the reference's order
+// (world.rs:195-201: by photon, then by bounce) with no sorting and no guess at the buffer's size.
+template <typename R, bool STORE>
 __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhotonTrace &pt, uint32_t first, uint32_t stride, rtmi_photon *out,
-                                              unsigned long long *keys, unsigned long long *counters, Stats &st) {
+                                              uint32_t *counts, const uint32_t *offsets, unsigned long long *counters, Stats &st) {
     const R EPS = (R)RTMI_EPSILON;
     unsigned long long rays = 0, truncated = 0;
-    uint32_t next = first, idx = 0, bounce = 0, origin_leaf = NONE, origin_side = 0;
+    uint32_t next = first, idx = 0, bounce = 0, origin_leaf = NONE, origin_side = 0, mine = 0, base = 0;
+    bool flush = false; // (counting: photon idx has ended and its count is not written yet)
     int kind = PK_DIRECT;
     bool alive = false;
     Ray<R> ray = {mk<R>(0, 0, 0), mk<R>(0, 0, 1)};
@@ -1911,8 +1915,14 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
     for (uint32_t i = 0; i < sc.n_lights; ++i) total_power += light_power(sc.lights[i]);
     for (;;) {
         if (!alive) {
+            if constexpr (!STORE) {
+                if (flush) counts[idx] = mine;
+                flush = false;
+            }
             if (next >= pt.n_emit) break;
             idx = next;
+            mine = 0; flush = true;
+            if constexpr (STORE) base = offsets[idx];
             next = (pt.n_emit - next > stride) ? next + stride : pt.n_emit; // (no wrap-around near 2^32)
             rng_begin(rng, idx, 0);
             // World::emit_photon (world.rs:211-215): WeightedIndex over the lights' power
@@ -1959,7 +1969,7 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
         }
         const R p_absorb = (R)1 - pd_avg - spec - trans;
         if (!(p_absorb >= (R)0)) { // materials.rs:443-445 panics: the call fails and names the leaf
-            counters[PT_BAD_LEAF] = (unsigned long long)sc.leaf_orig[h.leaf] + 1ull;
+            if constexpr (!STORE) counters[PT_BAD_LEAF] = (unsigned long long)sc.leaf_orig[h.leaf] + 1ull;
             alive = false;
             continue;
         }
@@ -1969,11 +1979,11 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
         int choice = x < c0 ? 0 : x < c1 ? 1 : x < c2 ? 2 : 3;
         if (choice == 3 && !(trans > (R)0)) choice = spec > (R)0 ? 2 : pd_avg > (R)0 ? 1 : 0; // (x rounded up to the total)
         if (store && ((kind == PK_DIRECT && pt.enable_direct) || (kind == PK_DIFFUSE && pt.enable_diffuse) || (kind == PK_CAUSTIC && pt.enable_caustic))) {
-            const unsigned long long slot = atomicAdd(&counters[PT_STORED], 1ull); // world.rs:256-265
-            if (slot < (unsigned long long)pt.cap) {
-                store_photon(&out[slot], c.point, ray.d, power, pt.inv_n);
-                keys[slot] = ((unsigned long long)idx << 16) | (unsigned long long)(bounce - 1u);
+            if constexpr (STORE) { // world.rs:256-265
+                const unsigned long long slot = (unsigned long long)base + mine;
+                if (slot < (unsigned long long)pt.cap) store_photon(&out[slot], c.point, ray.d, power, pt.inv_n);
             }
+            mine++;
         }
         const uint32_t side_over = c.side_plus ? SIDE_PLUS : 0u, side_under = c.side_plus ? 0u : SIDE_PLUS;
         if (choice == 0) { alive = false; continue; }
@@ -2000,8 +2010,10 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
         }
         origin_leaf = h.leaf;
     }
-    if (rays) atomicAdd(&counters[PT_RAYS], rays);
-    if (truncated) atomicAdd(&counters[PT_TRUNCATED], truncated);
+    if constexpr (!STORE) {
+        if (rays) atomicAdd(&counters[PT_RAYS], rays);
+        if (truncated) atomicAdd(&counters[PT_TRUNCATED], truncated);
+    }
 }
 
 // Camera::ray_for_pixel (camera.rs:120-153)

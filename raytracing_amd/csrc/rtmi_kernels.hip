@@ -771,8 +771,8 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
 }
 
 // World::compute_photon_map's tracing half (rtmi_trace_photons): lane l of the grid traces photons l, l + lanes, ...
-template <typename R>
-__global__ void __launch_bounds__(64) photon_trace_kernel(DScene<R> sc, DPhotonTrace pt, rtmi_photon *out, unsigned long long *keys,
+template <typename R, bool STORE>
+__global__ void __launch_bounds__(64) photon_trace_kernel(DScene<R> sc, DPhotonTrace pt, rtmi_photon *out, uint32_t *counts, const uint32_t *offsets,
                                                           unsigned long long *counters) {
     Stats st;
 #pragma unroll
@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(64) photon_trace_kernel(DScene<R> sc, DPhotonT
 #ifdef RTMI_CYCLES
     st.cyc[0] = st.cyc[1] = st.cyc[2] = st.cyc[3] = 0;
 #endif
-    trace_photons<R>(sc, pt, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, out, keys, counters, st);
+    trace_photons<R, STORE>(sc, pt, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, out, counts, offsets, counters, st);
 }
 
 // Camera::ray_for_pixel for a batch of (px, py, sample) (rtmi_camera_rays)
@@ -852,9 +852,10 @@ void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint3
     else hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
 }
 template <>
-void launch_photon_trace_kernel<RTMI_REAL>(int grid, hipStream_t st, const DScene<RTMI_REAL> &sc, const DPhotonTrace &pt, rtmi_photon *out,
-                                           unsigned long long *keys, unsigned long long *counters) {
-    hipLaunchKernelGGL(photon_trace_kernel<RTMI_REAL>, dim3(grid), dim3(64), 0, st, sc, pt, out, keys, counters);
+void launch_photon_trace_kernel<RTMI_REAL>(bool store, int grid, hipStream_t st, const DScene<RTMI_REAL> &sc, const DPhotonTrace &pt, rtmi_photon *out,
+                                           uint32_t *counts, const uint32_t *offsets, unsigned long long *counters) {
+    if (store) hipLaunchKernelGGL((photon_trace_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, st, sc, pt, out, counts, offsets, counters);
+    else hipLaunchKernelGGL((photon_trace_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, st, sc, pt, out, counts, offsets, counters);
 }
 template <>
 void launch_camera_rays_kernel<RTMI_REAL>(int grid, const DCamera<double> &cam, uint32_t seed_lo, uint32_t seed_hi, long long n,

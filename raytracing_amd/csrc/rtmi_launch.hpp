@@ -114,10 +114,10 @@ template <typename R>
 void launch_camera_rays_kernel(int grid, const DCamera<double> &cam, uint32_t seed_lo, uint32_t seed_hi, long long n, const int *px,
                                const int *py, const int *sample, double *origins, double *dirs);
 template <typename R>
-void launch_photon_trace_kernel(int grid, hipStream_t st, const DScene<R> &sc, const DPhotonTrace &pt, rtmi_photon *out, unsigned long long *keys,
-                                unsigned long long *counters);
-template <> void launch_photon_trace_kernel<float>(int, hipStream_t, const DScene<float> &, const DPhotonTrace &, rtmi_photon *, unsigned long long *, unsigned long long *);
-template <> void launch_photon_trace_kernel<double>(int, hipStream_t, const DScene<double> &, const DPhotonTrace &, rtmi_photon *, unsigned long long *, unsigned long long *);
+void launch_photon_trace_kernel(bool store, int grid, hipStream_t st, const DScene<R> &sc, const DPhotonTrace &pt, rtmi_photon *out, uint32_t *counts,
+                                const uint32_t *offsets, unsigned long long *counters);
+template <> void launch_photon_trace_kernel<float>(bool, int, hipStream_t, const DScene<float> &, const DPhotonTrace &, rtmi_photon *, uint32_t *, const uint32_t *, unsigned long long *);
+template <> void launch_photon_trace_kernel<double>(bool, int, hipStream_t, const DScene<double> &, const DPhotonTrace &, rtmi_photon *, uint32_t *, const uint32_t *, unsigned long long *);
 template <> void launch_render_kernel<float>(bool, int, int, hipStream_t, const DScene<float> &, const DCamera<double> &, const DRender &, float *, unsigned long long *, void *, size_t, hipEvent_t, void *);
 template <> void launch_render_kernel<double>(bool, int, int, hipStream_t, const DScene<double> &, const DCamera<double> &, const DRender &, float *, unsigned long long *, void *, size_t, hipEvent_t, void *);
 template <> void launch_trace_kernel<float>(int, const DScene<float> &, uint32_t, uint32_t, long long, const double *, const double *, const int *, double *, rtmi_hit_record *);

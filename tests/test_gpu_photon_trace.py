@@ -134,3 +134,23 @@ def test_full_size_population():
     assert abs(gst["n_rays"] / n - rst["n_rays"] / m) < 0.02 * rst["n_rays"] / m
     assert abs(cases.power_of(got).sum() - cases.power_of(ref).sum()) < 0.02 * cases.power_of(ref).sum()
     assert np.isfinite(got["position"]).all() and np.isfinite(got["direction"]).all()
+
+
+def test_the_threaded_balance_builds_the_same_tree():
+    """PhotonMap::balance on host threads (maps of 200,000 photons and more) against the one-thread order of work: the
+    same kd-tree, so the same frame bit for bit"""
+    import os
+    world, cam = scenes.photon_box(64, 64, deterministic=True, direct=False)
+    world.enable_direct_photon_map(True)
+    res = world.compute_photon_map(400000, 40, 0.3, seed=12)
+    assert res["n_stored"] > 300000
+    os.environ["RTMI_HOST_THREADS"] = "1"
+    try:
+        one = abi.Scene(world)
+    finally:
+        del os.environ["RTMI_HOST_THREADS"]
+    many = abi.Scene(world)
+    a, _ = abi.render_host(one, cam)
+    b, _ = abi.render_host(many, cam)
+    one.close(); many.close()
+    assert np.array_equal(a, b) and a.mean() > 0.02
