@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device); 0 = 2, and 3 with 4 GPUs or more "
                          "(measured shares of the headline frame, ms per frame with 2 / 3 in flight: 1/4 of it 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
-    ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice (BASELINE configurations) | photons | yard")
+    ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice (BASELINE configurations) | photons | yard | photonbox")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--sampling", default="shipped", choices=["shipped", "1spp"])
@@ -58,7 +58,8 @@ def workload_name(a):
              "ch11b": "chapter-11b water reflection/refraction, depth 5", "teapot": "chapter-15 teapot mesh in host-built BVH",
              "soft": "soft_shadow sphere light", "dof": "depth-of-field thin lens", "dice": "chapter-16 CSG dice + lens",
              "photons": "photon_room with a map of 2 M photons, 100 nearest per estimate (not a BASELINE configuration)",
-             "yard": "yard of every item kind (not a BASELINE configuration)"}
+             "yard": "yard of every item kind (not a BASELINE configuration)",
+             "photonbox": "examples/photon-map.rs room with a device-traced map of 2 M emitted photons, 100 nearest within 0.1 (not a BASELINE configuration)"}
     samp = "adaptive multisampling as shipped" if a.sampling == "shipped" else "1 centred sample per pixel"
     if a.max_samples:
         samp += " capped at %d samples/pixel" % a.max_samples

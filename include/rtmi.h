@@ -164,7 +164,7 @@ typedef struct rtmi_scene_desc {
     /* World::photon_map (world.rs:18,186-209) for the gather of Phong::shade_hit (materials.rs:376-384).
      * The photons as compute_photon_map collected them (world.rs:195-201), in any order: the library
      * balances them into the reference's kd-tree itself (PhotonMap::from_vec, photon_map.rs:230-313).
-     * Tracing photons is not part of this library.  n_photons == 0 (or photon_map_enabled() false,
+     * rtmi_trace_photons (below) produces such an array.  n_photons == 0 (or photon_map_enabled() false,
      * world.rs:124-128): no map, the branch is not taken.                                          */
     int64_t n_photons;
     const rtmi_photon *photons;

@@ -531,7 +531,16 @@ SCHEME_GOLDENS = {
     "chapter16": (scheme_chapter16, False),
 }
 
-EXTRA_SCENES = {"photons": photon_room_with_map, "yard": yard}  # (bench.py --scene takes these too; not BASELINE configurations)
+def photon_box_with_map(h=600, v=600, deterministic=False, n_photons=2_000_000, n_nearest=100, max_search_radius=0.1):
+    """examples/photon-map.rs' third picture (lines 106-118: direct light plus diffuse and caustic photons, 100 nearest within
+    0.1) with n_photons instead of its 75 M; the map is traced on the device (World::compute_photon_map -> rtmi_trace_photons)"""
+    w, cam = photon_box(h, v, deterministic=deterministic)
+    w.enable_direct_photon_map(False); w.enable_diffuse_photon_map(True); w.enable_caustic_photon_map(True)
+    w.compute_photon_map(n_photons, n_nearest, max_search_radius)
+    return w, cam
+
+
+EXTRA_SCENES = {"photons": photon_room_with_map, "yard": yard, "photonbox": photon_box_with_map}  # (bench.py --scene takes these too; not BASELINE configurations)
 
 BASELINE_SCENES = {
     "ch07": chapter07,
