@@ -14,6 +14,7 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 using namespace rtmi_dev;
@@ -885,17 +886,94 @@ static long long kd_left_children(long long n) { // compute_number_of_left_child
     const long long full = 1ll << depth, last = n - (full - 1);
     return last <= full / 2 ? (full - 2) / 2 + last : (full - 2) / 2 + full / 2;
 }
+template <typename F> static void on_threads(int n_threads, F f) { // f(0) .. f(n_threads - 1), the first on the calling thread
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(f, t);
+    f(0);
+    for (auto &th : pool) th.join();
+}
+struct KdKey { float p[3]; uint32_t idx; }; // position beside the index: the selection reads 16-byte records in place, no chase into the photons
+struct KdLess { // the order of partition_by_key's keys; equal keys by index (the reference leaves them to its partial sort)
+    int axis;
+    bool operator()(const KdKey &a, const KdKey &b) const { return a.p[axis] < b.p[axis] || (a.p[axis] == b.p[axis] && a.idx < b.idx); }
+};
+// std::nth_element for the few long ranges at the top of the tree: quickselect whose partition passes run on all threads
+// (each thread counts, then moves its chunk's elements to their side in `tmp`), down to a range one thread finishes.
+// The order is total (indices are distinct), so the k-th element and the SETS on its two sides are the ones
+// std::nth_element gives; the order inside the sides differs and does not matter: every later choice is by key again.
+static void parallel_select(KdKey *base, long long count, long long k, int axis, KdKey *tmp, int n_threads, long long serial_below) {
+    const KdLess less{axis};
+    long long lo = 0, hi = count;
+    while (hi - lo > serial_below && n_threads > 1) {
+        const long long len = hi - lo, chunk = (len + n_threads - 1) / n_threads;
+        KdKey sample[9];
+        for (int i = 0; i < 9; ++i) sample[i] = base[lo + (len - 1) * i / 8];
+        std::sort(sample, sample + 9, less);
+        const KdKey pivot = sample[4];
+        std::vector<long long> n_less((size_t)n_threads, 0), at_less((size_t)n_threads, 0), at_rest((size_t)n_threads, 0);
+        on_threads(n_threads, [&](int t) {
+            const long long a = std::min(hi, lo + t * chunk), b = std::min(hi, a + chunk);
+            long long c = 0;
+            for (long long i = a; i < b; ++i) c += less(base[i], pivot) ? 1 : 0;
+            n_less[(size_t)t] = c;
+        });
+        long long total_less = 0;
+        for (int t = 0; t < n_threads; ++t) total_less += n_less[(size_t)t];
+        if (total_less == 0 || total_less == len) break; // (the pivot is an end of the range: let one thread finish it)
+        long long run_less = 0, run_rest = total_less;
+        for (int t = 0; t < n_threads; ++t) {
+            const long long a = std::min(hi, lo + t * chunk), b = std::min(hi, a + chunk);
+            at_less[(size_t)t] = run_less; at_rest[(size_t)t] = run_rest;
+            run_less += n_less[(size_t)t]; run_rest += (b - a) - n_less[(size_t)t];
+        }
+        on_threads(n_threads, [&](int t) {
+            const long long a = std::min(hi, lo + t * chunk), b = std::min(hi, a + chunk);
+            KdKey *pl = tmp + at_less[(size_t)t], *pr = tmp + at_rest[(size_t)t];
+            for (long long i = a; i < b; ++i) {
+                if (less(base[i], pivot)) *pl++ = base[i];
+                else *pr++ = base[i];
+            }
+        });
+        on_threads(n_threads, [&](int t) {
+            const long long a = std::min(hi, lo + t * chunk), b = std::min(hi, a + chunk);
+            if (b > a) memcpy(base + a, tmp + (a - lo), (size_t)(b - a) * sizeof(KdKey));
+        });
+        if (k < lo + total_less) hi = lo + total_less;
+        else lo = lo + total_less;
+    }
+    std::nth_element(base + lo, base + k, base + hi, less);
+}
 // The recursion of PhotonMap::balance works on disjoint ranges of the photons and writes disjoint nodes: the top of the
-// tree is split on the calling thread until there are enough subtrees, which host threads (at most 16, RTMI_HOST_THREADS)
-// then take one at a time.  Keys sit next to their indices, so the selection reads 8-byte pairs instead of chasing photons.
+// tree is split level by level (its long selections on all host threads, parallel_select) until there are enough subtrees,
+// which the host threads (at most 16, RTMI_HOST_THREADS) then take one at a time.
 static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) {
+    int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const char *env_threads = getenv("RTMI_HOST_THREADS");
+    if (env_threads) n_threads = std::max(1, std::min(64, atoi(env_threads)));
+    else if (n < 200000) n_threads = 1;
+    long long pselect_min = 400000; // ranges this long are selected on all threads
+    if (const char *e = getenv("RTMI_PSELECT_MIN")) pselect_min = std::max(64ll, atoll(e));
     std::vector<DPhoton> out((size_t)n);
-    struct KI { float key; uint32_t idx; };
-    std::vector<KI> ki((size_t)n);
-    for (long long i = 0; i < n; ++i) ki[(size_t)i].idx = (uint32_t)i;
+    using KI = KdKey;
+    std::vector<KI> ki((size_t)n), tmp;
+    if (n_threads > 1 && n > pselect_min) tmp.resize((size_t)n);
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}; // compute_extent, photon_map.rs:415-421
-    for (long long i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], (double)ph[i].position[a]); hi[a] = std::fmax(hi[a], (double)ph[i].position[a]); }
+    {
+        const int T = n >= 200000 ? n_threads : 1;
+        std::vector<std::array<double, 6>> ext((size_t)T);
+        on_threads(T, [&](int t) {
+            const long long a = n * t / T, b = n * (t + 1) / T;
+            std::array<double, 6> e = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (long long i = a; i < b; ++i) {
+                KI &q = ki[(size_t)i];
+                q.idx = (uint32_t)i;
+                for (int c = 0; c < 3; ++c) { q.p[c] = ph[i].position[c]; e[(size_t)c] = std::fmin(e[(size_t)c], (double)q.p[c]); e[(size_t)c + 3] = std::fmax(e[(size_t)c + 3], (double)q.p[c]); }
+            }
+            ext[(size_t)t] = e;
+        });
+        for (const auto &e : ext)
+            for (int c = 0; c < 3; ++c) { lo[c] = std::fmin(lo[c], e[(size_t)c]); hi[c] = std::fmax(hi[c], e[(size_t)c + 3]); }
+    }
     struct Job { long long first, count, node; double lo[3], hi[3]; };
     auto put = [&](long long node, uint32_t i, uint32_t flag) {
         DPhoton &q = out[(size_t)node];
@@ -904,44 +982,46 @@ static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) 
         q.rgbf = (uint32_t)ph[i].power_rgb[0] | ((uint32_t)ph[i].power_rgb[1] << 8) | ((uint32_t)ph[i].power_rgb[2] << 16) | (flag << 24);
     };
     // one node: the split photon into its place, the two sides appended to `todo`
-    auto step = [&](const Job &j, std::vector<Job> &todo) {
+    auto step = [&](const Job &j, std::vector<Job> &todo, bool alone) { // alone: no other thread is at work, the long selections may use them all
         if (j.count == 0 || j.node >= n) return;
         if (j.count == 1) { put(j.node, ki[(size_t)j.first].idx, KD_LEAF); return; }
         const long long n_left = kd_left_children(j.count);
         const double sx = j.hi[0] - j.lo[0], sy = j.hi[1] - j.lo[1], sz = j.hi[2] - j.lo[2];
         const int axis = (sx >= sy && sx >= sz) ? 0 : ((sy >= sx && sy >= sz) ? 1 : 2); // photon_map.rs:270-294
         KI *base = ki.data() + j.first;
-        for (long long i = 0; i < j.count; ++i) base[i].key = ph[base[i].idx].position[axis];
-        // partition_by_key(n_left, ..): the n_left smallest keys in front, the next one at n_left (equal keys: by index -
-        // the reference leaves them to its partial sort)
-        std::nth_element(base, base + n_left, base + j.count, [](const KI &a, const KI &b) { return a.key < b.key || (a.key == b.key && a.idx < b.idx); });
+        // partition_by_key(n_left, ..): the n_left smallest keys in front, the next one at n_left
+        if (alone && !tmp.empty() && j.count > pselect_min) parallel_select(base, j.count, n_left, axis, tmp.data(), n_threads, pselect_min / 4);
+        else std::nth_element(base, base + n_left, base + j.count, KdLess{axis});
         const uint32_t m = base[n_left].idx;
-        const double median = (double)ph[m].position[axis];
+        const double median = (double)base[n_left].p[axis];
         put(j.node, m, (uint32_t)(KD_SPLIT_X + axis));
         Job l = j, r = j;
         l.count = n_left; l.node = 2 * (j.node + 1) - 1; l.hi[axis] = median;            // Aabb::split_*, aabb.rs:105-127
         r.first = j.first + n_left + 1; r.count = j.count - n_left - 1; r.node = 2 * (j.node + 1); r.lo[axis] = median;
         todo.push_back(l); todo.push_back(r);
     };
-    int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char *e = getenv("RTMI_HOST_THREADS")) n_threads = std::max(1, std::min(64, atoi(e)));
-    if (n < 200000) n_threads = 1;
+    const bool timing = getenv("RTMI_TIMING") != nullptr; // (diagnostic: the phases of the build to stderr)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "balance_photons %lld: %s at %.1f ms\n", n, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     std::vector<Job> level, next;
     Job root = {0, n, 0, {lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
     level.push_back(root);
     // breadth first until every thread has a few subtrees to take (one thread: the loop below does it all)
     while (n_threads > 1 && !level.empty() && level.size() < (size_t)n_threads * 4) {
         next.clear();
-        for (const Job &j : level) step(j, next);
+        for (const Job &j : level) step(j, next, true);
         level.swap(next);
     }
+    lap("top levels split");
     auto subtree = [&](const Job &top) {
         std::vector<Job> todo;
         todo.push_back(top);
         while (!todo.empty()) {
             const Job j = todo.back();
             todo.pop_back();
-            step(j, todo);
+            step(j, todo, false);
         }
     };
     if (n_threads <= 1) {
@@ -953,6 +1033,7 @@ static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) 
             pool.emplace_back([&]() { for (size_t k; (k = taken.fetch_add(1)) < level.size();) subtree(level[k]); });
         for (auto &th : pool) th.join();
     }
+    lap("subtrees done");
     return out;
 }
 

@@ -150,7 +150,14 @@ def test_the_threaded_balance_builds_the_same_tree():
     finally:
         del os.environ["RTMI_HOST_THREADS"]
     many = abi.Scene(world)
+    os.environ["RTMI_PSELECT_MIN"] = "50000"  # the top levels' selections on all threads too (parallel_select; default: ranges above 400,000)
+    try:
+        more = abi.Scene(world)
+    finally:
+        del os.environ["RTMI_PSELECT_MIN"]
+    c, _ = abi.render_host(more, cam)
+    more.close()
     a, _ = abi.render_host(one, cam)
     b, _ = abi.render_host(many, cam)
     one.close(); many.close()
-    assert np.array_equal(a, b) and a.mean() > 0.02
+    assert np.array_equal(a, b) and np.array_equal(a, c) and a.mean() > 0.02
