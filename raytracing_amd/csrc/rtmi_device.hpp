@@ -1581,75 +1581,102 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
 }
 
 // The photon-map term of Phong::shade_hit (materials.rs:376-384): PhotonMap::find_nearest (photon_map.rs:315-364) with the
-// recursion of locate_photons unrolled onto a stack (stage 0: descend to the near side; 1: back from it, the far side if
-// its plane is within the search radius and nearer than the farthest candidate; 2: the node's own photon, after both
-// sides as in the reference) and its BinaryHeap as two per-lane arrays; then the fold over the photons found.
+// recursion of locate_photons unrolled into a walk with stages per node (0: descend to the near side; 1: back from it, the
+// far side if its plane is within the search radius and nearer than the farthest candidate; 2: the node's own photon,
+// after both sides as in the reference) and its BinaryHeap as two per-lane arrays; then the fold over the photons found.
+template <typename R> struct HeapEntry { R d; uint32_t n; }; // a candidate of find_nearest: squared distance, node
+#ifndef RTMI_HEAP_ARITY
+#define RTMI_HEAP_ARITY 4
+#endif
+constexpr int HEAP_ARITY = RTMI_HEAP_ARITY;
 template <typename R>
 __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V3<R> normalv, V3<R> surface_color, Stats &st) {
     const uint32_t n = sc.n_photons;
     const int k = (int)min(sc.n_nearest, (uint32_t)RTMI_MAX_NEAREST);
-    R hd[RTMI_MAX_NEAREST];
-    uint32_t hn[RTMI_MAX_NEAREST];
+    HeapEntry<R> he[RTMI_MAX_NEAREST];
     int cnt = 0;
-    R top = (R)0; // hd[0] while cnt > 0, in a register: it is looked at for every photon visited
-    uint32_t stk[PHOTON_STACK];
-    int sp = 0;
+    R top = (R)0; // he[0].d while cnt > 0, in a register: it is looked at for every photon visited
     const R pc[3] = {p.x, p.y, p.z};
-    if (n > 0 && k > 0) stk[sp++] = 0u;
     uint32_t visited = 0;
-    while (sp > 0) {
-        const uint32_t e = stk[--sp];
-        const uint32_t node = e >> 2, stage = e & 3u;
-        if (node >= n) continue;
+    // No stack: the tree is in heap order (parent of i: (i - 1) / 2), so the way back is arithmetic, and the stage each
+    // ancestor is in (0: its near side is next; 1: back from it; 2: back from the far side) takes two bits per level of a
+    // 64-bit word - the tree of 2^30 - 1 photons has 30 levels.
+    uint32_t node = 0, depth = 0;
+    unsigned long long stages = 0;
+    bool walking = n > 0 && k > 0;
+    while (walking) { // (node < n here)
         const DPhoton &ph = sc.photons[node];
-        const uint32_t left = 2u * (node + 1u) - 1u;
+        const uint32_t left = 2u * node + 1u;
+        const uint32_t stage = (uint32_t)(stages >> (2u * depth)) & 3u;
         bool self = stage == 2u || left >= n; // (is_leaf, photon_map.rs:376-378)
         if (!self) {
             const uint32_t axis = min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u);
             const R d = pc[axis] - (R)ph.pos[axis];
-            const uint32_t near = d < (R)0 ? left : left + 1u, far = d < (R)0 ? left + 1u : left;
-            if (sp + 2 > PHOTON_STACK) { st.c[RTMI_STAT_OVERFLOW] = 1; self = true; } // (never: the tree is balanced)
-            else if (stage == 0u) { stk[sp++] = (node << 2) | 1u; stk[sp++] = near << 2; }
-            else if ((d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < top)) { stk[sp++] = (node << 2) | 2u; stk[sp++] = far << 2; }
+            uint32_t child = NONE;
+            unsigned long long next_stage = 0;
+            if (stage == 0u) { child = d < (R)0 ? left : left + 1u; next_stage = 1ull; }
+            else if ((d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < top)) { child = d < (R)0 ? left + 1u : left; next_stage = 2ull; }
             else self = true;
+            if (!self) {
+                stages = (stages & ~(3ull << (2u * depth))) | (next_stage << (2u * depth));
+                if (child < n && depth < 31u) { // down (a child beyond the photons returns at once, photon_map.rs:330-332: this node again, next stage)
+                    node = child; ++depth;
+                    stages &= ~(3ull << (2u * depth));
+                }
+                continue;
+            }
         }
-        if (self) {
+        {
             const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
             const R d2 = dx * dx + dy * dy + dz * dz;
             ++visited;
-            if (cnt < k || d2 < top) {
-                if (cnt == k) { // BinaryHeap::pop: the last entry to the root, then down
-                    --cnt;
-                    hd[0] = hd[cnt]; hn[0] = hn[cnt];
-                    int i = 0;
-                    for (;;) {
-                        const int l = 2 * i + 1, r = l + 1;
-                        int m = i;
-                        if (l < cnt && hd[m] < hd[l]) m = l;
-                        if (r < cnt && hd[m] < hd[r]) m = r;
-                        if (m == i) break;
-                        const R td = hd[m]; hd[m] = hd[i]; hd[i] = td;
-                        const uint32_t tn = hn[m]; hn[m] = hn[i]; hn[i] = tn;
-                        i = m;
-                    }
-                }
-                int i = cnt++; // BinaryHeap::push: at the end, then up
-                hd[i] = d2; hn[i] = node;
+            // BinaryHeap (photon_map.rs:354-362) as one array of (distance, node) pairs, a max-heap with HEAP_ARITY
+            // children per entry (half the levels of a binary one: every level is a round trip to per-lane memory).
+            // Not full: push = a hole at the end that climbs while its parent is nearer.  Full and this photon nearer
+            // than the farthest: pop + push = the farthest (the root) leaves and the hole it leaves sinks, the farthest
+            // child moving up, to where the new photon belongs - one pass.  The photons kept and the farthest distance
+            // are those of the reference's heap; their order inside the array - the order of the sum below - may
+            // differ from it, i.e. the sum in its last bits.
+            if (cnt < k) {
+                int i = cnt++;
                 while (i > 0) {
-                    const int q = (i - 1) / 2;
-                    if (!(hd[q] < hd[i])) break;
-                    const R td = hd[q]; hd[q] = hd[i]; hd[i] = td;
-                    const uint32_t tn = hn[q]; hn[q] = hn[i]; hn[i] = tn;
+                    const int q = (i - 1) / HEAP_ARITY;
+                    const HeapEntry<R> e = he[q];
+                    if (!(e.d < d2)) break;
+                    he[i] = e;
                     i = q;
                 }
-                top = hd[0];
+                he[i].d = d2; he[i].n = node;
+                top = he[0].d;
+            } else if (d2 < top) {
+                int i = 0;
+                for (;;) {
+                    const int c0 = HEAP_ARITY * i + 1;
+                    if (c0 >= cnt) break;
+                    const int last = cnt - 1;
+                    HeapEntry<R> c = he[c0];
+                    int m = c0;
+#pragma unroll
+                    for (int j = 1; j < HEAP_ARITY; ++j) { // (independent loads: one round trip per level; a clamped index repeats the last child)
+                        const int at = min(c0 + j, last);
+                        const HeapEntry<R> e = he[at];
+                        if (c.d < e.d) { c = e; m = at; }
+                    }
+                    if (!(d2 < c.d)) break;
+                    he[i] = c;
+                    i = m;
+                }
+                he[i].d = d2; he[i].n = node;
+                top = he[0].d;
             }
         }
+        if (depth == 0u) walking = false; // back to the parent
+        else { node = (node - 1u) >> 1; --depth; }
     }
     const R square_radius = cnt ? top : (R)1; // (unwrap_or(1.0), photon_map.rs:318)
     V3<R> total = mk<R>(0, 0, 0);
     for (int i = 0; i < cnt; ++i) {
-        const DPhoton &ph = sc.photons[min(hn[i], n - 1u)];
+        const DPhoton &ph = sc.photons[min(he[i].n, n - 1u)];
         const R w = max_(dot(normalv, mk<R>((R)ph.dir[0], (R)ph.dir[1], (R)ph.dir[2])), (R)0);
         const R x = (R)ph.scale;
         // decompress_color (photon_map.rs:41-47): byte * scale / 255

@@ -11,6 +11,9 @@ using namespace rtmi_dev;
 #ifndef RTMI_WAVES
 #define RTMI_WAVES 3 // minimum waves per SIMD the flat-scene render kernels are register-allocated for (168 VGPRs)
 #endif
+#ifndef RTMI_WAVES_PHOTON
+#define RTMI_WAVES_PHOTON 3 // ... the kernels that gather from a photon map
+#endif
 #ifndef RTMI_WAVES_TREE
 #define RTMI_WAVES_TREE 3 // ... and the tree-scene kernels
 #endif
@@ -210,7 +213,7 @@ __device__ __forceinline__ void keep_state(DPixelState<R> *__restrict__ state, s
 // appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
 template <typename R, bool TREE, bool SPREAD, bool PHOTON = false, bool DRAW = false>
-__global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
                                                     uint32_t wk_cap, DPixelState<R> *__restrict__ state) {
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *
 // counted from its own first-pass count, whoever computes them and however many were computed ahead: the image does
 // not depend on queue order, sharding, promotion or the prediction, bit for bit.
 template <typename R, bool TREE, bool PHOTON = false>
-__global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                       const DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
                                                       uint32_t *__restrict__ wk_final, uint32_t *__restrict__ wk_unit_pixel, uint32_t wk_cap,
@@ -673,7 +676,7 @@ __global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resam
 // leaves colours and counters in the unit's DChunk.
 constexpr int UNIT_BATCH_MAX = 16;
 template <typename R, bool TREE, bool PHOTON = false>
-__global__ void __launch_bounds__(64, TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
+__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
                                                    const DWorkItem<R> *__restrict__ wk_heavy, const uint32_t *__restrict__ wk_unit_pixel,
                                                    DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass) {
     stage_scene<R, TREE>(sc);
