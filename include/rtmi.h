@@ -364,6 +364,11 @@ typedef struct rtmi_photon_opts {
     int32_t enable_caustic;  /* World::enable_caustic_photon_map (world.rs:66: true)                   */
     int32_t max_bounces;     /* 0 = RTMI_PHOTON_BOUNCES                                                */
     int32_t reserved;
+    int64_t first;           /* this call traces the photons first .. first + count - 1 of the n_emit:  */
+    int64_t count;           /*   a share of the map (count 0 = all from `first` on).  Photon i draws    */
+                             /*   from its own stream and is scaled by 1 / n_emit, so the shares of any  */
+                             /*   split, one after the other, ARE the whole call's photons: ranks trace  */
+                             /*   disjoint shares and exchange the arrays, no other collective           */
 } rtmi_photon_opts;
 #define RTMI_PHOTON_BOUNCES 256
 typedef struct rtmi_photon_result {

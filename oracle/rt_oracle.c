@@ -1339,7 +1339,8 @@ int64_t orc_trace_photons(const rtmi_scene_desc *sc, const rtmi_photon_opts *o, 
     if (!(total_power > 0.0)) { free(lw); ctx_done(&cx); return -1; }
     const float inv_n = (float)(1.0 / (double)o->n_emit);
     int64_t result = 0;
-    for (int64_t idx = 0; idx < o->n_emit && result >= 0; ++idx) {
+    const int64_t idx_end = o->count > 0 ? o->first + o->count : o->n_emit; /* the call's share of the photons */
+    for (int64_t idx = o->first; idx < idx_end && result >= 0; ++idx) {
         rng_t g = {o->seed ^ ((uint64_t)0x50484F54u << 32), (uint32_t)idx, 0, 0};
         ray_t ray; v3 power;
         int li = weighted_index(lw, sc->n_lights, rng_next(&g)); /* world.rs:211-215 */

@@ -40,7 +40,7 @@ class HitRecord(C.Structure):
 
 class PhotonOpts(C.Structure):  # rtmi_photon_opts
     _fields_ = [("seed", C.c_uint64), ("n_emit", C.c_int64), ("precision", C.c_int32), ("enable_direct", C.c_int32), ("enable_diffuse", C.c_int32),
-                ("enable_caustic", C.c_int32), ("max_bounces", C.c_int32), ("reserved", C.c_int32)]
+                ("enable_caustic", C.c_int32), ("max_bounces", C.c_int32), ("reserved", C.c_int32), ("first", C.c_int64), ("count", C.c_int64)]
 
 
 class PhotonResult(C.Structure):  # rtmi_photon_result
@@ -228,9 +228,9 @@ def photon_dtype():
                      ("reserved", np.uint8)])  # rtmi_photon, 32 bytes
 
 
-def make_photon_opts(n_emit, seed=0x5EED, precision=0, direct=False, diffuse=True, caustic=True, max_bounces=0):
+def make_photon_opts(n_emit, seed=0x5EED, precision=0, direct=False, diffuse=True, caustic=True, max_bounces=0, first=0, count=0):
     """The flags default to World::new's (world.rs:64-66)."""
-    return PhotonOpts(seed, n_emit, precision, int(direct), int(diffuse), int(caustic), max_bounces, 0)
+    return PhotonOpts(seed, n_emit, precision, int(direct), int(diffuse), int(caustic), max_bounces, 0, first, count)
 
 
 def trace_photons(scene, opts, capacity=None):

@@ -1828,7 +1828,10 @@ extern "C" int rtmi_trace_photons(const rtmi_scene *scene, const rtmi_photon_opt
         return fail(RTMI_ERR_DEVICE, "the scene lives on device " + std::to_string(scene->device) + " but the current HIP device is " + std::to_string(dev));
     DPhotonTrace pt;
     pt.seed_lo = (uint32_t)opts->seed; pt.seed_hi = (uint32_t)(opts->seed >> 32) ^ 0x50484F54u;
-    pt.n_emit = (uint32_t)opts->n_emit;
+    if (opts->first < 0 || opts->first >= opts->n_emit || opts->count < 0 || opts->count > opts->n_emit - opts->first)
+        return fail(RTMI_ERR_INVALID, "first = " + std::to_string(opts->first) + ", count = " + std::to_string(opts->count) + " is not a share of n_emit = " + std::to_string(opts->n_emit));
+    const long long share = opts->count > 0 ? opts->count : opts->n_emit - opts->first;
+    pt.first = (uint32_t)opts->first; pt.end = (uint32_t)(opts->first + share); pt.pad = 0;
     pt.max_bounces = (uint32_t)(opts->max_bounces > 0 ? opts->max_bounces : RTMI_PHOTON_BOUNCES);
     pt.enable_direct = opts->enable_direct != 0; pt.enable_diffuse = opts->enable_diffuse != 0; pt.enable_caustic = opts->enable_caustic != 0;
     pt.direct_only = pt.enable_direct && !pt.enable_caustic && !pt.enable_diffuse;
@@ -1837,8 +1840,8 @@ extern "C" int rtmi_trace_photons(const rtmi_scene *scene, const rtmi_photon_opt
     const bool f64 = opts->precision == RTMI_PRECISION_F64;
     // lanes: enough waves to fill the GPU a few times over, never more lanes than photons
     const long long waves_wanted = (long long)scene->num_cu * 16;
-    const int grid = (int)std::max<long long>(1, std::min<long long>(waves_wanted, (opts->n_emit + 63) / 64));
-    const uint32_t n = pt.n_emit, nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(waves_wanted, (share + 63) / 64));
+    const uint32_t n = (uint32_t)share, nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     rtmi_photon *d_out = nullptr;
     uint32_t *d_counts = nullptr, *d_offsets = nullptr;
     unsigned long long *d_sums = nullptr, *d_cnt = nullptr;

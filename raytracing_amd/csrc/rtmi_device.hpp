@@ -1833,7 +1833,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
 // ---------------------------------------------------------------------------------------------
 struct DPhotonTrace {
     uint32_t seed_lo, seed_hi; // (the photon stream's key: the caller's seed with "PHOT" xored into the high word)
-    uint32_t n_emit, max_bounces;
+    uint32_t first, end, max_bounces, pad; // this call's photons: first .. end - 1 (counts / offsets are indexed from `first`)
     uint32_t enable_direct, enable_diffuse, enable_caustic, direct_only; // world.rs:64-66,130-134
     float inv_n;  // scale_power(1 / n_photons), world.rs:200
     uint32_t cap; // photons `out` holds (the storing pass)
@@ -1930,7 +1930,7 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
                                               uint32_t *counts, const uint32_t *offsets, unsigned long long *counters, Stats &st) {
     const R EPS = (R)RTMI_EPSILON;
     unsigned long long rays = 0, truncated = 0;
-    uint32_t next = first, idx = 0, bounce = 0, origin_leaf = NONE, origin_side = 0, mine = 0, base = 0;
+    uint32_t next = pt.end - pt.first > first ? pt.first + first : pt.end, idx = 0, bounce = 0, origin_leaf = NONE, origin_side = 0, mine = 0, base = 0;
     bool flush = false; // (counting: photon idx has ended and its count is not written yet)
     int kind = PK_DIRECT;
     bool alive = false;
@@ -1943,14 +1943,14 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
     for (;;) {
         if (!alive) {
             if constexpr (!STORE) {
-                if (flush) counts[idx] = mine;
+                if (flush) counts[idx - pt.first] = mine;
                 flush = false;
             }
-            if (next >= pt.n_emit) break;
+            if (next >= pt.end) break;
             idx = next;
             mine = 0; flush = true;
-            if constexpr (STORE) base = offsets[idx];
-            next = (pt.n_emit - next > stride) ? next + stride : pt.n_emit; // (no wrap-around near 2^32)
+            if constexpr (STORE) base = offsets[idx - pt.first];
+            next = (pt.end - next > stride) ? next + stride : pt.end; // (no wrap-around near 2^32)
             rng_begin(rng, idx, 0);
             // World::emit_photon (world.rs:211-215): WeightedIndex over the lights' power
             const R x = rng_next<R>(rng) * total_power;

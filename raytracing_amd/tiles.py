@@ -84,3 +84,32 @@ class RowGather:
         if self.rank != self.dst:
             return None
         return self.assemble(self.parts)
+
+
+# ------------------------------------------------------------------------------------------------
+# photon map: ranks trace disjoint shares of the photons (rtmi_photon_opts.first / count) and exchange the arrays
+# ------------------------------------------------------------------------------------------------
+def photon_share(n_emit, rank, nranks):
+    """(first, count) of rank's share of n_emit photons: contiguous blocks in rank order, so the shares one after the other
+    are the photons of the whole call in the reference's order (world.rs:195-201)."""
+    nranks = max(int(nranks), 1)
+    first = n_emit * rank // nranks
+    return first, n_emit * (rank + 1) // nranks - first
+
+
+def all_gather_photons(local, group=None):
+    """Every rank's stored photons (a uint8 tensor [n_r, 32] of rtmi_photon records, on the device the backend moves: the
+    GPU under RCCL) -> the whole map [sum n_r, 32] on every rank, shares in rank order.  Two collectives: the counts, then
+    the records padded to the largest share - every rank needs the whole map, because every rank renders with it."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    n = dist.get_world_size(group)
+    count = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(count) for _ in range(n)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    padded = torch.zeros((max(max(counts), 1), 32), dtype=torch.uint8, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.zeros_like(padded) for _ in range(n)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)

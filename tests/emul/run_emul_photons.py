@@ -29,5 +29,9 @@ for name, make, flags in cases.CASES:
         got, gst = abi.trace_photons(sc, opts)
         print("%-12s %s emitted %d  stored %d / %d  rays %d / %d  %s" % (name, "f64" if prec else "f32", n, gst["n_stored"], rst["n_stored"], gst["n_rays"],
                                                                          rst["n_rays"], cases.compare(got, gst, ref, rst, exact=bool(prec))), flush=True)
+    # a map in shares (rtmi_photon_opts.first / count): one after the other they are the whole call's photons
+    whole, _ = abi.trace_photons(sc, abi.make_photon_opts(n, seed=11, **flags))
+    parts = [abi.trace_photons(sc, abi.make_photon_opts(n, seed=11, first=a, count=c, **flags))[0] for a, c in ((0, n // 3), (n // 3, n - n // 3 - 7), (n - 7, 0))]
+    assert np.array_equal(np.concatenate(parts), whole)
     sc.close()
 print("emulation run clean")

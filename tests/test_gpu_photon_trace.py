@@ -161,3 +161,23 @@ def test_the_threaded_balance_builds_the_same_tree():
     b, _ = abi.render_host(many, cam)
     one.close(); many.close()
     assert np.array_equal(a, b) and np.array_equal(a, c) and a.mean() > 0.02
+
+
+@pytest.mark.parametrize("precision", [1, 0], ids=["f64", "f32"])
+def test_shares_one_after_the_other_are_the_whole_call(precision):
+    """rtmi_photon_opts.first / count (how ranks divide a map): any split gives the one-call photons bit for bit"""
+    from raytracing_amd import tiles
+    world = cases.lights_room()
+    sc = abi.Scene(world)
+    n = 30011
+    whole, wst = abi.trace_photons(sc, abi.make_photon_opts(n, seed=17, precision=precision, direct=True))
+    for k in (2, 5):
+        parts, rays = [], 0
+        for r in range(k):
+            first, count = tiles.photon_share(n, r, k)
+            ph, st = abi.trace_photons(sc, abi.make_photon_opts(n, seed=17, precision=precision, direct=True, first=first, count=count))
+            parts.append(ph); rays += st["n_rays"]
+        assert np.array_equal(np.concatenate(parts), whole) and rays == wst["n_rays"]
+    with pytest.raises(abi.RtmiError, match="share"):
+        abi.trace_photons(sc, abi.make_photon_opts(n, first=n - 5, count=10))
+    sc.close()

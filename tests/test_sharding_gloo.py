@@ -88,3 +88,47 @@ def test_single_rank_gather_is_identity():
     assert torch.equal(g.gather(local), local)
     with pytest.raises(ValueError):
         g.gather(local[:10])
+
+
+def _photon_worker(rank, world_size, port, n_emit, q):
+    """The photon map's N > 1 path: every rank traces its share of the photons (here the oracle stands in for
+    rtmi_trace_photons; tests/test_gpu_photon_trace.py checks that the device call honours first / count the same way) and
+    all ranks end up with the whole map, in the order of the one-call map."""
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        import photon_trace_cases as cases
+        flat = cases.box().flatten()
+        first, count = tiles.photon_share(n_emit, rank, world_size)
+        mine, _ = orc.trace_photons(flat, abi.make_photon_opts(n_emit, seed=3, direct=True, first=first, count=count))
+        local = torch.from_numpy(np.ascontiguousarray(mine).view(np.uint8).reshape(-1, 32).copy())
+        whole = tiles.all_gather_photons(local)
+        ref, _ = orc.trace_photons(flat, abi.make_photon_opts(n_emit, seed=3, direct=True))
+        q.put(bool(np.array_equal(whole.numpy().reshape(-1).view(orc.PHOTON_DTYPE), ref)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,n_emit", [(2, 5000), (3, 1001)])
+def test_photon_shares_gather_to_the_whole_map(world_size, n_emit):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_photon_worker, args=(r, world_size, port, n_emit, q)) for r in range(world_size)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _ in range(world_size):
+        assert q.get(timeout=5) is True
+
+
+def test_photon_shares_partition_the_photons():
+    for n in (1, 2, 7, 1000, 2_000_001):
+        for k in (1, 2, 3, 8):
+            shares = [tiles.photon_share(n, r, k) for r in range(k)]
+            assert shares[0][0] == 0 and sum(c for _, c in shares) == n
+            assert all(shares[i][0] + shares[i][1] == shares[i + 1][0] for i in range(k - 1))
