@@ -1589,13 +1589,27 @@ template <typename R> struct HeapEntry { R d; uint32_t n; }; // a candidate of f
 #define RTMI_HEAP_ARITY 4
 #endif
 constexpr int HEAP_ARITY = RTMI_HEAP_ARITY;
+#ifndef RTMI_HEAP_LDS
+#define RTMI_HEAP_LDS 21
+#endif
+constexpr int HEAP_LDS = RTMI_HEAP_LDS; // entries of the heap held in LDS (21: the top three levels at arity 4; measured 5 / 21 / 37 / 53 / 85: 356 / 256 / 317 / 394 / 425 ms on the 4K photon frame, 382 with none - more LDS per wave costs waves per CU)
 template <typename R>
 __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V3<R> normalv, V3<R> surface_color, Stats &st) {
     const uint32_t n = sc.n_photons;
     const int k = (int)min(sc.n_nearest, (uint32_t)RTMI_MAX_NEAREST);
     HeapEntry<R> he[RTMI_MAX_NEAREST];
+    // The top levels - where most passes through the heap begin and end (a photon that replaces the farthest is seldom
+    // much nearer than it) - live in LDS, [entry][lane]: these are the lines that every pass would otherwise pull through
+    // the memory system from per-lane scratch (PMC: 515 GB moved per 1920x1080 frame, 12 x the photons read, before).  (One wave per workgroup: the lane is threadIdx.x & 63.)
+    __shared__ HeapEntry<R> heap_top[HEAP_LDS][64];
+    const int heap_lane = (int)(threadIdx.x & 63u);
+    auto heap_ld = [&](int i) -> HeapEntry<R> { return i < HEAP_LDS ? heap_top[i][heap_lane] : he[i]; };
+    auto heap_st = [&](int i, const HeapEntry<R> &e) {
+        if (i < HEAP_LDS) heap_top[i][heap_lane] = e;
+        else he[i] = e;
+    };
     int cnt = 0;
-    R top = (R)0; // he[0].d while cnt > 0, in a register: it is looked at for every photon visited
+    R top = (R)0; // the root's distance while cnt > 0, in a register: it is looked at for every photon visited
     const R pc[3] = {p.x, p.y, p.z};
     uint32_t visited = 0;
     // No stack: the tree is in heap order (parent of i: (i - 1) / 2), so the way back is arithmetic, and the stage each
@@ -1641,33 +1655,35 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
                 int i = cnt++;
                 while (i > 0) {
                     const int q = (i - 1) / HEAP_ARITY;
-                    const HeapEntry<R> e = he[q];
+                    const HeapEntry<R> e = heap_ld(q);
                     if (!(e.d < d2)) break;
-                    he[i] = e;
+                    heap_st(i, e);
                     i = q;
                 }
-                he[i].d = d2; he[i].n = node;
-                top = he[0].d;
+                heap_st(i, HeapEntry<R>{d2, node});
+                top = i == 0 ? d2 : top;
             } else if (d2 < top) {
                 int i = 0;
+                R new_top = d2;
                 for (;;) {
                     const int c0 = HEAP_ARITY * i + 1;
                     if (c0 >= cnt) break;
                     const int last = cnt - 1;
-                    HeapEntry<R> c = he[c0];
+                    HeapEntry<R> c = heap_ld(c0);
                     int m = c0;
 #pragma unroll
                     for (int j = 1; j < HEAP_ARITY; ++j) { // (independent loads: one round trip per level; a clamped index repeats the last child)
                         const int at = min(c0 + j, last);
-                        const HeapEntry<R> e = he[at];
+                        const HeapEntry<R> e = heap_ld(at);
                         if (c.d < e.d) { c = e; m = at; }
                     }
                     if (!(d2 < c.d)) break;
-                    he[i] = c;
+                    heap_st(i, c);
+                    if (i == 0) new_top = c.d;
                     i = m;
                 }
-                he[i].d = d2; he[i].n = node;
-                top = he[0].d;
+                heap_st(i, HeapEntry<R>{d2, node});
+                top = new_top;
             }
         }
         if (depth == 0u) walking = false; // back to the parent
@@ -1676,7 +1692,7 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
     const R square_radius = cnt ? top : (R)1; // (unwrap_or(1.0), photon_map.rs:318)
     V3<R> total = mk<R>(0, 0, 0);
     for (int i = 0; i < cnt; ++i) {
-        const DPhoton &ph = sc.photons[min(he[i].n, n - 1u)];
+        const DPhoton &ph = sc.photons[min(heap_ld(i).n, n - 1u)];
         const R w = max_(dot(normalv, mk<R>((R)ph.dir[0], (R)ph.dir[1], (R)ph.dir[2])), (R)0);
         const R x = (R)ph.scale;
         // decompress_color (photon_map.rs:41-47): byte * scale / 255
