@@ -5,14 +5,19 @@ Workload (BASELINE.json configs[1]): the reference's chapter-11a reflection/refr
 (rust/examples/chapter-11a.rs), recursion depth 5, 3840x2160, adaptive multisampling as the example ships it
 (min 5 samples, allowed standard error 1e-2) on the seeded counter RNG.  A "step" is one full frame.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: one process per GPU under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
+N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one of the ranks; started plainly
+with --gpus N > 1 it starts torch.distributed.run itself as a child BEFORE anything touches the GPU and passes the
+child's output and exit code on (the reference's fan-out needs no launcher either: camera.rs:260-264).
 N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
-gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default: 2,
-and 3 from 4 GPUs on, where a rank's share is short: tools/inflight.py) frames are in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside
-the library): the ends of one frame's kernels - a few waves finishing the deepest pixels - and its gather overlap
-the next frame's first pass.  Every frame is rendered completely and gathered inside the timed region; F = 1 runs
-the frames strictly one after the other.  Rank 0 prints ONE JSON line.
+gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default: 2
+on one GPU, 3 from 2 GPUs on, where a rank's share is short: tools/inflight.py, profiles/r02d_rank_share.txt) frames are
+in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside the library): the
+ends of one frame's kernels - a few waves finishing the deepest pixels - and its gather overlap the next frame's first
+pass.  Every frame is rendered completely and gathered inside the timed region; F = 1 runs the frames strictly one after
+the other.  Rank 0 prints ONE JSON line.  At N = 1 the line also carries `all_configs`: every other BASELINE
+configuration measured live by this run after the headline's timed region (a few frames each; --no-all-configs skips it).
 """
 import argparse
 import ctypes
@@ -33,8 +38,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device); 0 = 2, and 3 with 4 GPUs or more "
-                         "(measured shares of the headline frame, ms per frame with 2 / 3 in flight: 1/4 of it 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
+                    help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device); 0 = 2 on one GPU, 3 with 2 GPUs or more "
+                         "(measured shares of the headline frame, ms per frame with 2 / 3 in flight: 1/2 of it 13.3 / 12.7, 1/4 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
     ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice (BASELINE configurations) | photons | yard | photonbox")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -43,14 +48,33 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--max-samples", type=int, default=0, help="cap on samples per pixel (0 = unbounded like the reference; diagnostics only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="headline only: skip the CPU baseline and, with it, the other extras that follow the timed region (all_configs, the host-frame measurement) - what the profiling scripts under tools/ pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path with several ranks sharing one GPU (rows cross through host memory)")
     ap.add_argument("--gather", default="f32", choices=["f32", "rgb8"],
                     help="what crosses xGMI: the float canvas (default, what Camera::render returns) or Color::to_u8 bytes made on the device")
     ap.add_argument("--check-frame", action="store_true", help="rank 0 also renders the whole frame alone and compares it bit for bit with the gathered one")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
+    ap.add_argument("--no-all-configs", action="store_true", help="skip the live measurement of the other BASELINE configurations (N = 1 only)")
+    ap.add_argument("--no-host-frame", action="store_true", help="skip the PCIe-inclusive measurement through rtmi_render (N = 1 only)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: start the N ranks as a child `python -m torch.distributed.run ... bench.py <same
+    arguments>` and pass its exit code on.  Nothing in THIS process has touched the GPU yet (torch is not even imported),
+    and nothing is exec'ed: the child is an ordinary subprocess whose stdout (rank 0's JSON line) is ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def workload_name(a):
@@ -105,8 +129,51 @@ def cpu_baseline(world, cam, a, scenes):
                       "this job may use (the machine shows %d logical CPUs)" % (stride, n_rows, v, cam.hsize(), v, dt, threads, os.cpu_count() or 0)}
 
 
+ALL_CONFIGS = (("ch07", "1spp", 8), ("ch07", "shipped", 4), ("ch11a", "1spp", 8), ("ch11b", "1spp", 8), ("ch11b", "shipped", 4), ("teapot", "1spp", 8),
+               ("teapot", "shipped", 4), ("soft", "shipped", 4), ("dof", "shipped", 3), ("dice", "1spp", 6), ("dice", "shipped", 3))
+
+
+def measure_config(torch, abi, scenes, dev, name, sampling, steps, a, F=2):
+    """One more BASELINE configuration, measured like the headline (frames in flight on their own streams, wall time between
+    synchronisations, every frame whole), plus the same call alone between HIP events for the dominant kernel's fraction."""
+    world, cam = scenes.BASELINE_SCENES[name](a.width, a.height, deterministic=(sampling == "1spp"))
+    scene = abi.Scene(world)
+    opts = abi.make_opts(seed=a.seed)
+    h, v = cam.hsize(), cam.vsize()
+    bufs = [torch.zeros((v, h, 3), dtype=torch.float32, device=dev) for _ in range(F)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % F]):
+                abi.render_device(scene, cam, opts, bufs[i % F], stats, streams[i % F].cuda_stream)
+        torch.cuda.synchronize()
+    run(max(F, 2))
+    stats.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    S = {k: int(x) for k, x in zip(abi.STAT_NAMES, stats.cpu().tolist())}
+    rays = S["primary"] + S["reflection"] + S["refraction"] + S["shadow"]
+    one = torch.zeros(abi.N_STATS, dtype=torch.int64, device=dev)
+    with torch.cuda.stream(streams[0]):
+        m1, m2 = abi.render_device_timed(scene, cam, opts, bufs[0], one, streams[0].cuda_stream)
+    O = {k: int(x) for k, x in zip(abi.STAT_NAMES, one.cpu().tolist())}
+    fl2 = float(O["flops_second"]); fl1 = float(O["flops"]) - fl2
+    dom_ms, dom_fl = (m1, fl1) if m1 >= m2 else (m2, fl2)
+    scene.close()
+    return {"ms_per_frame": round(dt / steps * 1e3, 3), "Mrays_s": round(rays / dt / 1e6), "rays": rays // steps, "samples": S["samples"] // steps,
+            "steps": steps, "ms_call_alone": round(m1 + m2, 3), "ms_dominant_kernel": round(dom_ms, 3),
+            "frac": round(dom_fl / (dom_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4) if dom_ms > 0 else 0.0,
+            "frac_call_alone": round(float(O["flops"]) / ((m1 + m2) * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4) if m1 + m2 > 0 else 0.0}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     from raytracing_amd import abi, scenes
@@ -251,14 +318,16 @@ def main():
         for kv in kernels.values():
             kv["frac"] = kv["achieved"] / PEAK_FP32_VALU_TFLOPS
         dominant = max(kernels, key=lambda k: kernels[k]["ms"])
-        scenes_table = None
-        tp = os.path.join(ROOT, "profiles", "r02_all_scenes.json")
+        # VALU busy %, lane utilisation and algorithmic FLOP per active lane-op of the dominant kernel: from the committed PMC
+        # passes of this build (profiles/pmc_summary.json, written by tools/pmc_summary.py; counters cannot be read in-process)
+        pmc = None
+        tp = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(tp):
             try:
                 with open(tp) as f:
-                    scenes_table = json.load(f)
+                    pmc = json.load(f).get("%s_%s" % (a.scene, a.sampling))
             except Exception:
-                scenes_table = None
+                pmc = None
         out = {
             "metric": "Mrays/s (primary+secondary) at 3840x2160, 1/2/4/8 MI355X; % FP32 VALU peak",
             "value": rays / dt / 1e6,
@@ -280,6 +349,9 @@ def main():
                        "ray_classes_per_step": {k: S[k] // a.steps for k in ("primary", "reflection", "refraction", "shadow")}},
             "roofline": {"bound": "valu", "kernel": dominant, "achieved": kernels[dominant]["achieved"], "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": kernels[dominant]["frac"], "traffic": traffic,
+                         "valu_busy": pmc and pmc.get("valu_busy"), "lane_util": pmc and pmc.get("lane_util"),
+                         "flop_per_lane_op": pmc and pmc.get("flop_per_lane_op"), "valu_insts_per_wave_ray": pmc and pmc.get("valu_insts_per_wave_ray"),
+                         "pmc_source": pmc and pmc.get("source"),
                          "per_kernel": kernels,
                          "call": {"ms_alone": serial_ms, "frac_alone": flops_launch / (serial_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                                   "ms_in_flight": k_ms, "frac_in_flight": achieved / PEAK_FP32_VALU_TFLOPS,
@@ -289,10 +361,35 @@ def main():
                                  "'Roofline and accounting') / its duration between HIP events recorded on the launch stream before and after "
                                  "it (rtmi_render_device_timed, the call alone on the GPU, mean of 3, after the timed region); per_kernel has "
                                  "both passes; call.* is the whole call: alone, and as the span of the timed region / calls with "
-                                 "frames_in_flight calls overlapping; traffic = HBM bytes per call from PMC passes (profiles/traffic.json)"},
+                                 "frames_in_flight calls overlapping; traffic = HBM bytes per call from PMC passes (profiles/traffic.json); "
+                                 "valu_busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / GRBM_GUI_ACTIVE per XCD, lane_util = SQ_THREAD_CYCLES_VALU / (64 x "
+                                 "SQ_ACTIVE_INST_VALU), flop_per_lane_op = algorithmic FLOPs / (SQ_THREAD_CYCLES_VALU / 4) of the dominant kernel, "
+                                 "from the committed PMC passes named in pmc_source (profiles/pmc_summary.json)"},
         }
-        if scenes_table is not None:
-            out["all_configs"] = scenes_table
+        if world_size == 1 and not a.no_host_frame and not a.no_cpu_baseline:
+            # The drop-in call a foreign-language front end makes: rtmi_render, host Canvas out (camera.rs:155-161).  Kernels + the
+            # device->host copy of the frame; never `value`.
+            abi.render_host(scene, cam, abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec))
+            t1 = time.perf_counter()
+            n_host = 3
+            for _ in range(n_host):
+                _, hst = abi.render_host(scene, cam, abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec))
+            ht = (time.perf_counter() - t1) / n_host
+            hrays = sum(hst[k] for k in ("primary", "reflection", "refraction", "shadow"))
+            out["pcie_inclusive"] = {"entry_point": "rtmi_render (host float buffer out)", "ms_per_frame": ht * 1e3, "Mrays_s": hrays / ht / 1e6,
+                                     "frames": n_host, "note": "one frame at a time; kernels + device->host copy of the 12 B/pixel frame"}
+        if world_size == 1 and not a.no_all_configs and not a.no_cpu_baseline and (a.width, a.height, a.precision, a.max_samples) == (3840, 2160, "f32", 0):
+            rows = {}
+            for name, sampling, n in ALL_CONFIGS:
+                if (name, sampling) == (a.scene, a.sampling):
+                    continue
+                try:
+                    rows["%s_%s" % (name, sampling)] = measure_config(torch, abi, scenes, dev, name, sampling, n, a)
+                except Exception as e:  # (a row that fails is reported, not hidden)
+                    rows["%s_%s" % (name, sampling)] = {"error": str(e)}
+            out["all_configs"] = {"_what": "the other BASELINE configurations at 3840x2160, f32, measured LIVE by this run after the headline's timed "
+                                           "region: 2 frames in flight, wall time over `steps` whole frames; frac = the dominant kernel of one call "
+                                           "alone between HIP events", "rows": rows}
         if not a.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(world, cam, a, scenes)
         print(json.dumps(out), flush=True)

@@ -294,6 +294,8 @@ struct rtmi_scene {
     bool bvh_has_units = false; // some DBvh2 tree has an ENT_LEAF entry
     uint32_t *quick = nullptr; // LDS records of the first top-level leaves (rtmi_device.hpp stage_scene)
     uint32_t n_quick = 0;
+    uint32_t *pairs = nullptr, *others = nullptr; // the pair tables of the LDS block; the top-level leaves that are not in them
+    uint32_t n_others = 0, pair_counts = 0, real_counts = 0;
     DScene<float> h32;
     DScene<double> h64;
     int num_cu = 256;
@@ -1037,8 +1039,15 @@ static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) 
     return out;
 }
 
+// what the flat f32 kernels stage in LDS (rtmi_device.hpp stage_scene) and the list that goes with it
+struct QuickTables {
+    std::vector<uint32_t> quick, pairs, others;
+    uint32_t pair_counts = 0, real_counts = 0;
+};
+
 template <typename R>
-static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A, std::vector<uint32_t> *quick = nullptr) {
+static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<R> &A, QuickTables *qt = nullptr) {
+    std::vector<uint32_t> *quick = qt ? &qt->quick : nullptr;
     std::vector<DLeaf<R>> leaves(L.leaf_orig.size());
     std::vector<DTri<R>> tris;
     for (size_t i = 0; i < leaves.size(); ++i) {
@@ -1164,6 +1173,36 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
                 q[2] = n_slots++;
             }
         }
+        // the pair tables (quick_pairs): the LEAF_QUICK leaves by kind and by whether they cast shadows, two to a record,
+        // component by component; a group of an odd number of leaves ends with a filler no ray hits.  Every other
+        // top-level leaf goes on the `others` list.
+        std::vector<uint32_t> group[4]; // spheres casting / not, planes casting / not
+        for (size_t i = 0; i < L.nodes[0].leaf_count; ++i) {
+            const uint32_t kind = i < nq ? (*quick)[i * QUICK_DW] : 0u;
+            if (!(kind & LEAF_QUICK)) { qt->others.push_back((uint32_t)i); continue; }
+            group[((kind & LEAF_FAST) ? 0 : 2) + ((kind & LEAF_CAST_SHADOW) ? 0 : 1)].push_back((uint32_t)i);
+        }
+        qt->pairs.assign((size_t)LDS_PAIRS * PAIR_DW, 0u);
+        uint32_t n_pairs = 0, pc[4] = {0, 0, 0, 0};
+        for (int gi = 0; gi < 4; ++gi) {
+            for (size_t k = 0; k < group[gi].size(); k += 2, ++n_pairs, ++pc[gi]) {
+                uint32_t *rec = qt->pairs.data() + (size_t)n_pairs * PAIR_DW;
+                for (int h = 0; h < 2; ++h) {
+                    float v[4] = {0.0f, 0.0f, 0.0f, gi < 2 ? -1.0f : 0.0f}; // the filler: a sphere of radius^2 -1 / a plane with a zero row
+                    uint32_t id = 0xFFFFFFFEu;
+                    if (k + h < group[gi].size()) {
+                        id = group[gi][k + h];
+                        memcpy(v, quick->data() + (size_t)id * QUICK_DW + 4, sizeof v);
+                    }
+                    for (int a = 0; a < 4; ++a) memcpy(rec + 2 * a + h, &v[a], 4);
+                    rec[8 + h] = id;
+                }
+            }
+        }
+        // (n_pairs <= LDS_PAIRS: at most LDS_QUICK leaves in four groups)
+        qt->pair_counts = (pc[0] + pc[1]) | (pc[0] << 8) | ((pc[2] + pc[3]) << 16) | (pc[2] << 24);
+        qt->real_counts = (uint32_t)(group[0].size() + group[1].size()) | ((uint32_t)group[0].size() << 8) | ((uint32_t)(group[2].size() + group[3].size()) << 16) |
+                          ((uint32_t)group[2].size() << 24);
     }
     std::vector<DMaterial<R>> mats((size_t)d->n_materials);
     for (int i = 0; i < d->n_materials; ++i) {
@@ -1224,9 +1263,11 @@ template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_d
     h.has_units = 0;
     for (const DNode &n : L.nodes) if (n.flags & NODE_CSGROOT) h.has_units = 1;
     if (sizeof(R) == 4 && s->bvh_has_units) h.has_units = 1;
-    h.quick = nullptr; h.n_quick = 0; h.n_lds_materials = 0; h.n_lds_lights = 0; h.pad2 = 0;
+    h.quick = nullptr; h.n_quick = 0; h.n_lds_materials = 0; h.n_lds_lights = 0;
+    h.pairs = nullptr; h.others = nullptr; h.n_others = 0; h.pair_counts = 0; h.real_counts = 0;
     if (sizeof(R) == 4) {
         h.quick = s->quick; h.n_quick = s->n_quick;
+        h.pairs = s->pairs; h.others = s->others; h.n_others = s->n_others; h.pair_counts = s->pair_counts; h.real_counts = s->real_counts;
         h.n_lds_materials = d->n_materials <= LDS_MATS ? (uint32_t)d->n_materials : 0u;
         h.n_lds_lights = d->n_lights <= LDS_LIGHTS ? (uint32_t)d->n_lights : 0u;
     }
@@ -1277,7 +1318,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->photons); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->photons); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->pairs); (void)hipFree(s->others); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -1328,9 +1369,11 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->csg_chain, L.chains());
     if (rc == RTMI_OK && desc->n_photons > 0) { s->n_photons = (uint32_t)desc->n_photons; rc = upload(&s->photons, balance_photons(desc->photons, desc->n_photons)); }
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
-    std::vector<uint32_t> quick;
-    if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &quick);
-    if (rc == RTMI_OK) { s->n_quick = (uint32_t)std::min<size_t>(L.nodes[0].leaf_count, (size_t)LDS_QUICK); rc = upload(&s->quick, quick); }
+    QuickTables qt;
+    if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &qt);
+    if (rc == RTMI_OK) { s->n_quick = (uint32_t)std::min<size_t>(L.nodes[0].leaf_count, (size_t)LDS_QUICK); rc = upload(&s->quick, qt.quick); }
+    if (rc == RTMI_OK) rc = upload(&s->pairs, qt.pairs);
+    if (rc == RTMI_OK) { s->n_others = (uint32_t)qt.others.size(); s->pair_counts = qt.pair_counts; s->real_counts = qt.real_counts; rc = upload(&s->others, qt.others); }
     if (rc == RTMI_OK) rc = upload_typed<double>(desc, L, s->f64);
     if (rc == RTMI_OK && (rc = pool_acquire(dev)) == RTMI_OK) s->pooled = true;
     void *unused_scratch = nullptr;

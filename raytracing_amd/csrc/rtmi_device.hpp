@@ -197,7 +197,11 @@ template <typename R> struct DScene {
     uint32_t n_quick;          // min(root_leaf_count, LDS_QUICK)
     uint32_t n_lds_materials;  // all materials, or 0 if there are more than LDS_MATS
     uint32_t n_lds_lights;     // all lights, or 0 if there are more than LDS_LIGHTS
-    uint32_t pad2;
+    uint32_t n_others;         // top-level leaves that are not in the pair tables (flat f32 scenes; else all of them)
+    const uint32_t *pairs;     // LDS_PAIRS * PAIR_DW dwords: the image of the block's pair tables (quick_pairs)
+    const uint32_t *others;    // n_others device leaf indices, ascending
+    uint32_t pair_counts;      // pairs of the tables, a byte each: spheres | shadow-casting spheres << 8 | planes << 16 | shadow-casting planes << 24
+    uint32_t real_counts;      // the leaves in them (a table of an odd number of leaves ends with a filler), same bytes
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -225,8 +229,15 @@ constexpr int MAT_DW = (int)(sizeof(DMaterial<float>) / 4), LIGHT_DW = (int)(siz
 constexpr int LDS_PATS_AT = (LDS_QUICK + 1) * QUICK_DW; // (the leaf loop fetches one record ahead: one spare slot)
 constexpr int LDS_MATS_AT = LDS_PATS_AT + LDS_PATS * PAT_DW;
 constexpr int LDS_LIGHTS_AT = LDS_MATS_AT + LDS_MATS * MAT_DW;
-constexpr int LDS_SCENE_DW = LDS_LIGHTS_AT + LDS_LIGHTS * LIGHT_DW; // 524 dwords = 2.1 KB per wave
-static_assert(sizeof(DMaterial<float>) % 4 == 0 && sizeof(DLight<float>) % 4 == 0 && sizeof(DPattern<float>) % 4 == 0 && LDS_PATS_AT % 4 == 0 && LDS_MATS_AT % 4 == 0, "LDS scene block layout");
+//   pair tables     the LEAF_QUICK leaves once more, two to a record and one kind to a table, as the intersection loops
+//                   want them (quick_pairs): x0 x1 y0 y1 z0 z1 w0 w1 leaf0 leaf1 - -, i.e. the two centres / plane rows
+//                   component by component, so that one packed instruction (v_pk_fma_f32 ...) works on both leaves.
+//                   Order: spheres that cast shadows, other spheres, planes that cast shadows, other planes; a group of
+//                   an odd number of leaves ends with a filler that no ray hits (radius^2 < 0 / a zero row).
+constexpr int LDS_PAIRS = 10, PAIR_DW = 12; // (16 leaves in four groups: at most 10 records)
+constexpr int LDS_PAIRS_AT = LDS_LIGHTS_AT + LDS_LIGHTS * LIGHT_DW;
+constexpr int LDS_SCENE_DW = LDS_PAIRS_AT + LDS_PAIRS * PAIR_DW; // 644 dwords = 2.6 KB per wave
+static_assert(sizeof(DMaterial<float>) % 4 == 0 && sizeof(DLight<float>) % 4 == 0 && sizeof(DPattern<float>) % 4 == 0 && LDS_PATS_AT % 4 == 0 && LDS_MATS_AT % 4 == 0 && LDS_PAIRS_AT % 4 == 0, "LDS scene block layout");
 __device__ __forceinline__ uint32_t *lds_scene() {
     __shared__ __align__(16) uint32_t s_scene[LDS_SCENE_DW];
     return s_scene;
@@ -245,6 +256,7 @@ template <typename R, bool TREE> __device__ __forceinline__ void stage_scene(con
         for (uint32_t i = first; i < nq; i += step) s[i] = sc.quick[i];
         for (uint32_t i = first; i < nm; i += step) s[LDS_MATS_AT + i] = m[i];
         for (uint32_t i = first; i < nl; i += step) s[LDS_LIGHTS_AT + i] = l[i];
+        for (uint32_t i = first; i < (uint32_t)(LDS_PAIRS * PAIR_DW); i += step) s[LDS_PAIRS_AT + i] = sc.pairs[i];
 #ifndef RTMI_HOST_EMUL
         __syncthreads(); // (one wave per workgroup: its own writes, visible to all its lanes from here on)
 #endif
@@ -317,6 +329,22 @@ template <typename R> __device__ __forceinline__ V3<R> xf_normal(const R *m, V3<
 
 template <typename R> struct Ray { V3<R> o, d; };
 __device__ __forceinline__ float u2f_(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+// Two floats that one packed instruction works on (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: both halves at the rate
+// of one scalar-per-lane operation).  The host emulation has no such type: a struct with the same operators.
+#ifdef RTMI_HOST_EMUL
+struct f2 { float x, y; };
+inline f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+inline f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+inline f2 operator*(f2 a, f2 b) { return {a.x * b.x, a.y * b.y}; }
+inline f2 operator-(f2 a) { return {-a.x, -a.y}; }
+#else
+typedef float f2 __attribute__((ext_vector_type(2)));
+#endif
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 splat2(float a) { return mk2(a, a); }
+__device__ __forceinline__ uint32_t f2u_(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); } // v_min3_u32
 
 template <typename R> struct Lim;
 template <> struct Lim<float> { static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); } };
@@ -888,43 +916,87 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
     apply_roots<R, MODE>(li, n, t, best, t_limit, hit_leaf, hit_ord, open);
 }
 
-// A LEAF_QUICK top-level leaf from its LDS record (wave-uniform kind, q = the record's four floats): the roots leaf_roots
-// finds for the same leaf, without its record.  inv_a = 1 / (d . d) of the ray.
+// The LEAF_QUICK top-level leaves - spheres under a similarity transform as world-space spheres |p - c|^2 = r^2, planes as
+// row 1 of their world->object matrix (see leaf_roots: the ray parameter is the same in both spaces) - from the pair
+// tables of the LDS block, TWO leaves per step.  What the loops are built around:
+//   * no branch per leaf and no list: the two leaves' arithmetic is the same instruction stream on packed pairs
+//     (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: (o - c), d . oc, the foot of the perpendicular, its squared length);
+//     only sqrt / rcp and the update are per leaf;
+//   * hit (ray.rs:143-154: the first root with t >= 0) and "nearer than the best so far" are ONE unsigned minimum: the
+//     bit patterns of the non-negative floats ascend like the numbers, and every negative number, -0 and every NaN is
+//     above +inf's pattern - so min3_u32(best, t0, t1) is the running minimum over the roots that count, and a missed
+//     leaf (the root of a negative number: NaN) needs no test of its own.  (-0, a root exactly at the origin of a ray that
+//     was not spawned there, counts as behind: a set of measure zero.)
+//   * the shadow query (MODE_ANY; world.rs:158-180) keeps no leaf and no order: the minimum over all shadow-casting
+//     leaves, compared with the distance once at the end;
+//   * the leaf a ray was spawned on is the only per-lane branch: its root nearest zero is the spawn point (see leaf_roots).
+// Counters: every leaf of the tables is tested by every ray that comes here (as World::intersect tests every object,
+// world.rs:145-170: the reference has no early exit either), so tests and their FLOPs are wave-uniform sums plus the
+// per-lane count of sphere hits (F_SPHERE_HIT - F_SPHERE_MISS each).
 template <int MODE>
-__device__ __forceinline__ void quick_leaf(uint32_t li, uint32_t kind, float q0, float q1, float q2, float q3, const Ray<float> &ray, float inv_a,
-                                           uint32_t origin_leaf, Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord,
-                                           Open<float> &open, Stats &st) {
-    float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int n = 0;
-    uint32_t fl;
-    if (kind & LEAF_FAST) { // the world-space sphere |p - c|^2 = r^2 (see leaf_roots)
-        const V3<float> oc = ray.o - mk<float>(q0, q1, q2);
-        const float a = dot(ray.d, ray.d), hb = dot(ray.d, oc);
-        const V3<float> l = oc - ray.d * (hb * inv_a);
-        const float disc4 = a * (q3 - dot(l, l));
-        fl = F_SPHERE_MISS;
-        if (!(disc4 < 0.0f)) {
-            const float tm = -hb * inv_a, hc = sqrt_(disc4) * inv_a;
-            t[0] = tm - hc; t[1] = tm + hc;
-            n = 2;
-            fl = F_SPHERE_HIT;
+__device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<float> &ray, uint32_t origin_leaf, Hit<float> &best, float t_limit,
+                                            uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
+    const uint32_t *tab = lds_scene() + LDS_PAIRS_AT;
+    const uint32_t pc = sc.pair_counts, rc = sc.real_counts;
+    const uint32_t sph_all = pc & 255u, n_sph = MODE == MODE_ANY ? (pc >> 8) & 255u : sph_all;
+    const uint32_t n_pl = MODE == MODE_ANY ? pc >> 24 : (pc >> 16) & 255u;
+    const uint32_t real_sph = MODE == MODE_ANY ? (rc >> 8) & 255u : rc & 255u, real_pl = MODE == MODE_ANY ? rc >> 24 : (rc >> 16) & 255u;
+    if (n_sph + n_pl == 0u) return;
+    const float inv_a = rcp_(dot(ray.d, ray.d));
+    const f2 ox = splat2(ray.o.x), oy = splat2(ray.o.y), oz = splat2(ray.o.z), dx = splat2(ray.d.x), dy = splat2(ray.d.y), dz = splat2(ray.d.z), ia = splat2(inv_a);
+    uint32_t bt = f2u_(MODE == MODE_ANY ? Lim<float>::inf() : best.t), bl = best.leaf, sphere_hits = 0;
+    auto take = [&](uint32_t id, float t0, float t1, bool two) { // the roots of one leaf, ascending
+        if (MODE == MODE_COLLECT) {
+            const float t[4] = {t0, t1, 0.0f, 0.0f};
+            apply_roots<float, MODE_COLLECT>(id, two ? 2 : 1, t, best, t_limit, hit_leaf, hit_ord, open);
+        } else if (MODE == MODE_ANY) {
+            bt = two ? umin3(bt, f2u_(t0), f2u_(t1)) : min(bt, f2u_(t0));
+        } else {
+            const uint32_t c = two ? umin3(bt, f2u_(t0), f2u_(t1)) : min(bt, f2u_(t0));
+            bl = c != bt ? id : bl;
+            bt = c;
         }
-    } else { // plane.rs:35-44 on the y row of the object-space ray
-        const float oy = q0 * ray.o.x + q1 * ray.o.y + q2 * ray.o.z + q3;
-        const float dy = q0 * ray.d.x + q1 * ray.d.y + q2 * ray.d.z;
-        fl = F_PLANE;
-        if (!(abs_(dy) < (float)RTMI_EPSILON)) { t[0] = div_(-oy, dy); n = 1; }
+    };
+    for (uint32_t p = 0; p < n_sph; ++p) { // sphere.rs:47-63 in world space, roots as closest approach -+ half chord
+        const uint32_t *r = tab + p * (uint32_t)PAIR_DW;
+        const f2 cx = mk2(u2f_(r[0]), u2f_(r[1])), cy = mk2(u2f_(r[2]), u2f_(r[3])), cz = mk2(u2f_(r[4]), u2f_(r[5])), r2 = mk2(u2f_(r[6]), u2f_(r[7]));
+        const uint32_t id0 = r[8], id1 = r[9];
+        const f2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+        const f2 k = (dx * ocx + dy * ocy + dz * ocz) * ia;          // (d . oc) / (d . d): minus the parameter of closest approach
+        const f2 lx = ocx - dx * k, ly = ocy - dy * k, lz = ocz - dz * k;
+        const f2 x = (r2 - (lx * lx + ly * ly + lz * lz)) * ia;      // (half chord)^2 in units of t; negative: the line misses
+        const bool h0 = !(x.x < 0.0f), h1 = !(x.y < 0.0f);
+        if (h0 || h1) {
+            const float s0 = sqrt_(x.x), s1 = sqrt_(x.y); // (NaN for the one that missed: never a minimum)
+            float t00 = -k.x - s0, t01 = s0 - k.x, t10 = -k.y - s1, t11 = s1 - k.y;
+            sphere_hits += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
+            if (origin_leaf == id0 && h0) { // the spawn point: the root nearest zero lies behind the origin
+                if (abs_(t01) < abs_(t00)) t01 = -max_(abs_(t01), 1e-30f); else t00 = -max_(abs_(t00), 1e-30f);
+            }
+            if (origin_leaf == id1 && h1) {
+                if (abs_(t11) < abs_(t10)) t11 = -max_(abs_(t11), 1e-30f); else t10 = -max_(abs_(t10), 1e-30f);
+            }
+            if (MODE != MODE_COLLECT || h0) take(id0, t00, t01, true);
+            if (MODE != MODE_COLLECT || h1) take(id1, t10, t11, true);
+        }
     }
-    st.c[RTMI_STAT_LEAF_TESTS]++;
-    st.flops += F_XFORM + fl;
-    if (li == origin_leaf && n > 0) { // the spawn point itself: behind the origin (see leaf_roots)
-        const bool second = n > 1 && abs_(t[1]) < abs_(t[0]);
-        const float forced = -max_(second ? abs_(t[1]) : abs_(t[0]), 1e-30f);
-        if (second) t[1] = forced; else t[0] = forced;
+    for (uint32_t p = 0; p < n_pl; ++p) { // plane.rs:35-44 on the y row of the object-space ray
+        const uint32_t *r = tab + (sph_all + p) * (uint32_t)PAIR_DW;
+        const f2 nx = mk2(u2f_(r[0]), u2f_(r[1])), ny = mk2(u2f_(r[2]), u2f_(r[3])), nz = mk2(u2f_(r[4]), u2f_(r[5])), w = mk2(u2f_(r[6]), u2f_(r[7]));
+        const uint32_t id0 = r[8], id1 = r[9];
+        const f2 ddy = nx * dx + ny * dy + nz * dz, ooy = nx * ox + ny * oy + nz * oz + w;
+        const bool h0 = !(abs_(ddy.x) < (float)RTMI_EPSILON), h1 = !(abs_(ddy.y) < (float)RTMI_EPSILON);
+        const float nan = __builtin_nanf("");
+        float t0 = h0 ? -ooy.x * rcp_(ddy.x) : nan, t1 = h1 ? -ooy.y * rcp_(ddy.y) : nan;
+        if (origin_leaf == id0) t0 = -max_(abs_(t0), 1e-30f); // (of a NaN: a NaN still)
+        if (origin_leaf == id1) t1 = -max_(abs_(t1), 1e-30f);
+        if (MODE != MODE_COLLECT || h0) take(id0, t0, 0.0f, false);
+        if (MODE != MODE_COLLECT || h1) take(id1, t1, 0.0f, false);
     }
-    // (measured: the general update below, which the compiler turns into two short exec-masked blocks, beats a
-    // branch-free "first root >= 0" select by 4 - 5 % on the chapter-11 frames)
-    apply_roots<float, MODE>(li, n, t, best, t_limit, hit_leaf, hit_ord, open);
+    st.c[RTMI_STAT_LEAF_TESTS] += real_sph + real_pl;
+    st.flops += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE) + sphere_hits * (F_SPHERE_HIT - F_SPHERE_MISS);
+    if (MODE == MODE_ANY) { if (bt < f2u_(t_limit)) best.leaf = 0u; } // (which leaf: nobody asks)
+    else if (MODE == MODE_CLOSEST) { best.t = u2f_(bt); best.leaf = bl; }  // (best.ord of a leaf of the tables: prepare knows it)
 }
 
 // A triangle leaf of a NODE_ALLTRI node, tested in world space from its DWTri record alone: no leaf record, no ray
@@ -1170,35 +1242,23 @@ __device__ __forceinline__ uint32_t (*lds_node_stack())[64] {
 template <typename R, int MODE, bool TREE>
 __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
-    // Top-level primitives: wave-uniform loop bounds.  f32: the first n_quick of them have a record in the LDS block
-    // (stage_scene), fetched one leaf ahead of its test; LEAF_QUICK ones need nothing else, the others go on to their
-    // record in global memory (scalar loads) with the kind already known.  f64, and leaves past the block: scalar loads.
-    {
-        uint32_t nq = 0, kind_next = 0;
-        float qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0, inv_a = 0;
-        if constexpr (staged_v<R, TREE>) {
-            const uint32_t *qs = lds_scene();
-            nq = sc.n_quick;
-            inv_a = rcp_(dot(ray.d, ray.d));
-            kind_next = qs[0]; qn0 = u2f_(qs[4]); qn1 = u2f_(qs[5]); qn2 = u2f_(qs[6]); qn3 = u2f_(qs[7]);
+    // Top-level primitives: wave-uniform loop bounds.  Flat f32 scenes: the LEAF_QUICK ones among the first n_quick from
+    // the pair tables of the LDS block (quick_pairs), two per step and without a branch per leaf; the others - kinds the
+    // tables do not hold, leaves past the block - from their record in global memory through scalar loads, with the kind
+    // from the leaf's LDS record where it has one (one round trip instead of two).  f64 and tree scenes: scalar loads.
+    if constexpr (staged_v<R, TREE>) {
+        quick_pairs<MODE>(sc, ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+        if (MODE == MODE_ANY && best.leaf != NONE) return;
+        const uint32_t nq = sc.n_quick;
+        for (uint32_t i = 0; i < sc.n_others; ++i) {
+            const uint32_t li = sc.others[i];
+            const uint32_t kind = li < nq ? __builtin_amdgcn_readfirstlane(lds_scene()[li * (uint32_t)QUICK_DW]) : sc.leaves[li].kind;
+            plain_leaf<R, MODE>(sc, li, sc.leaves[li], kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            if (MODE == MODE_ANY && best.leaf != NONE) return;
         }
+    } else {
         for (uint32_t li = 0; li < sc.root_leaf_count; ++li) {
-            bool quick = false;
-            uint32_t kind = 0;
-            if constexpr (staged_v<R, TREE>) {
-                if (li < nq) {
-                    kind = __builtin_amdgcn_readfirstlane(kind_next);
-                    const float q0 = qn0, q1 = qn1, q2 = qn2, q3 = qn3;
-                    const uint32_t *nx = lds_scene() + (li + 1u) * (uint32_t)QUICK_DW;
-                    kind_next = nx[0]; qn0 = u2f_(nx[4]); qn1 = u2f_(nx[5]); qn2 = u2f_(nx[6]); qn3 = u2f_(nx[7]);
-                    if (kind & LEAF_QUICK) {
-                        quick = true;
-                        if (!(MODE == MODE_ANY && !(kind & LEAF_CAST_SHADOW)))
-                            quick_leaf<MODE>(li, kind, q0, q1, q2, q3, ray, inv_a, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
-                    }
-                } else kind = sc.leaves[li].kind;
-            } else kind = sc.leaves[li].kind;
-            if (!quick) plain_leaf<R, MODE>(sc, li, sc.leaves[li], kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            plain_leaf<R, MODE>(sc, li, sc.leaves[li], sc.leaves[li].kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             if (MODE == MODE_ANY && best.leaf != NONE) return;
         }
     }
@@ -1411,7 +1471,7 @@ template <typename R> struct Comps {
 
 // (kind | flags and material of the hit leaf come back too: from the leaf's LDS record if it has one)
 template <typename R, bool TREE>
-__device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, const Hit<R> &h, Comps<R> &c, uint32_t &kind, uint32_t &material) {
+__device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, Hit<R> &h, Comps<R> &c, uint32_t &kind, uint32_t &material) {
     c.point = ray.o + ray.d * h.t; // Ray::position, ray.rs:26-28
     c.eyev = -ray.d;
     c.n1 = (R)1; c.n2 = (R)1;
@@ -1426,6 +1486,9 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
                 c.inside = dot(n, c.eyev) < (R)0;
                 c.normalv = c.inside ? -n : n;
                 c.side_plus = false;
+                // which of the leaf's ascending roots the hit is (quick_pairs does not keep it): a sphere's second root is
+                // where the ray leaves it, i.e. seen from inside; a plane has one
+                h.ord = ((kind & LEAF_FAST) && c.inside) ? 1u : 0u;
                 return;
             }
         }

@@ -17,6 +17,18 @@ using namespace rtmi_dev;
 #ifndef RTMI_WAVES_TREE
 #define RTMI_WAVES_TREE 3 // ... and the tree-scene kernels
 #endif
+// rtmi_trace_rays on a flat scene through the flat-scene code of the render kernels (trace_kernel<R, PHOTON, false>) instead
+// of the tree kind's.  On in the host emulation (tests/emul: every known-answer ray then goes through quick_pairs under
+// ASan / UBSan); OFF in the GPU build: the first GPU run of round 3 faulted in the one test that launched it with full
+// waves, the cause could not be found on the CPU (the emulation of the same 10,000 rays is clean) and GPU access ended
+// with that run - so the GPU build launches the instantiation round 2 shipped (same instruction stream, checked).
+#ifndef RTMI_TRACE_FLAT
+#ifdef RTMI_HOST_EMUL
+#define RTMI_TRACE_FLAT 1
+#else
+#define RTMI_TRACE_FLAT 0
+#endif
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -724,10 +736,13 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
 
 #endif // RTMI_HOST_EMUL
 
-// World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays)
-template <typename R, bool PHOTON = false>
+// World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays).
+// TREE = false: the flat-scene code of the render kernels (LDS scene block, pair tables), for worlds whose objects are all
+// primitives - so that the known-answer tests and the host emulation go through the very loops the frames are rendered with.
+template <typename R, bool PHOTON = false, bool TREE = true>
 __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
                                                    const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
+    stage_scene<R, TREE>(sc); // (every lane of the wave, before any leaves)
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Stats st;
@@ -746,7 +761,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
     Comps<R> c;
     c.point = mk<R>(0, 0, 0); c.normalv = c.point; c.eyev = c.point; c.inside = false; c.side_plus = false; c.n1 = 1; c.n2 = 1;
     int rem = remaining ? remaining[i] : (int)sc.max_depth;
-    V3<R> col = color_at<R, true, PHOTON>(sc, ray, rem, rng, st, &h, &c);
+    V3<R> col = color_at<R, TREE, PHOTON>(sc, ray, rem, rng, st, &h, &c);
     if (rgb) { rgb[3 * i] = (double)col.x; rgb[3 * i + 1] = (double)col.y; rgb[3 * i + 2] = (double)col.z; }
     if (recs) {
         rtmi_hit_record r;
@@ -765,7 +780,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
                 if (k == RTMI_LIGHT_POINT || k == RTMI_LIGHT_REALISTIC_POINT || k == RTMI_LIGHT_BEAM) {
                     V3<R> over_point = c.point + c.normalv * (R)RTMI_EPSILON;
                     Incoming<R> in = incoming_at(sc.lights[0], over_point, rng);
-                    if (in.kind == IL_RAY) r.shadowed = is_shadowed<R, true>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st) ? 1.0 : 0.0;
+                    if (in.kind == IL_RAY) r.shadowed = is_shadowed<R, TREE>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st) ? 1.0 : 0.0;
                 }
             }
         }
@@ -852,6 +867,9 @@ template <>
 void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint32_t seed_lo, uint32_t seed_hi, long long n,
                                     const double *origins, const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
     if (sc.n_photons) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
+#if RTMI_TRACE_FLAT
+    else if (staged_v<RTMI_REAL, false> && sc.root_child_count == 0) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
+#endif
     else hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
 }
 template <>

@@ -45,17 +45,24 @@ for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof
     c32, r32 = abi.trace_rays(sc, o, d, opts=abi.make_opts(precision=0))
     bad = 0
     same32 = 0
+    col32 = 0
     for i in range(n):
         ref = orc.hit_record(f, o[i], d[i])
         g = r64[i]
         ok = g.hit == ref.hit and (not ref.hit or (g.leaf == ref.leaf and abs(g.t - ref.t) < 1e-7 * max(1.0, abs(ref.t)) and (g.n1, g.n2) == (ref.n1, ref.n2)))
-        if ok and name not in ("soft", "gallery"):  # (scenes with randomly sampled lights: colours are compared by the image tests)
-            ok = bool(np.all(np.abs(c64[i] - orc.color_at(f, o[i], d[i], world.max_reflection_depth)[1]) < 1e-9))
+        if name not in ("soft", "gallery"):  # (scenes with randomly sampled lights: colours are compared by the image tests)
+            rc = orc.color_at(f, o[i], d[i], world.max_reflection_depth)[1]
+            if ok:
+                ok = bool(np.all(np.abs(c64[i] - rc) < 1e-9))
+            # the f32 product path (flat scenes: the LDS block and pair tables of the render kernels): colour to 1/255, n1 / n2 of the first hit
+            col32 += int(bool(np.all(np.abs(c32[i] - rc) < 4e-3)) and (not ref.hit or r32[i].leaf != ref.leaf or (abs(r32[i].n1 - ref.n1) < 1e-6 and abs(r32[i].n2 - ref.n2) < 1e-6)))
+        else:
+            col32 += 1
         bad += 0 if ok else 1
         same32 += int(r32[i].hit == ref.hit and (not ref.hit or r32[i].leaf == ref.leaf or abs(r32[i].t - ref.t) < 1e-5 * max(1.0, ref.t)))
     px = rng.integers(0, 32, 64).astype(np.int32); py = rng.integers(0, 16, 64).astype(np.int32)
     abi.camera_rays(cam, px, py, np.arange(64, dtype=np.int32), opts=abi.make_opts(precision=0))
     sc.close()
-    print("%-7s rays %d  f64 mismatches vs oracle %d  f32 same leaf %.2f %%" % (name, n, bad, 100.0 * same32 / n), flush=True)
-    assert bad == 0 and same32 >= 0.995 * n
+    print("%-7s rays %d  f64 mismatches vs oracle %d  f32 same leaf %.2f %%  f32 colour within 4e-3 and same n1/n2 %.2f %%" % (name, n, bad, 100.0 * same32 / n, 100.0 * col32 / n), flush=True)
+    assert bad == 0 and same32 >= 0.995 * n and col32 >= 0.98 * n
 print("emulation run clean")
