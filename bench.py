@@ -198,6 +198,8 @@ def main():
 
     build = scenes.BASELINE_SCENES.get(a.scene) or scenes.EXTRA_SCENES[a.scene]
     world, cam = build(a.width, a.height, deterministic=(a.sampling == "1spp"))
+    F = a.frames_in_flight if a.frames_in_flight > 0 else (3 if world_size >= 2 else 2)
+    os.environ.setdefault("RTMI_WORK_SLOTS_PREALLOC", str(F))  # one work-queue slot per stream, made with the scene: no allocation on the enqueue path
     scene = abi.Scene(world)
     prec = 0 if a.precision == "f32" else 1
     opts = abi.make_opts(seed=a.seed, max_samples=a.max_samples, precision=prec, rank=rank, nranks=world_size, tile_rows=a.tile_rows)
@@ -205,7 +207,6 @@ def main():
     from raytracing_amd import tiles
     gather = tiles.RowGather(v, h, tile_rows=a.tile_rows, device=xdev, dtype=torch.uint8 if a.gather == "rgb8" else torch.float32)
     assert gather.rows == abi.rank_rows(v, rank, world_size, a.tile_rows)
-    F = a.frames_in_flight if a.frames_in_flight > 0 else (3 if world_size >= 2 else 2)
     NB = max(F, 2)  # buffers: at least two, so that frame i+1 renders while frame i is gathered even with one stream
     bufs = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.float32, device=dev) for _ in range(NB)]
     bufs8 = [torch.zeros((gather.padded_rows, h, 3), dtype=torch.uint8, device=dev) for _ in range(NB)] if a.gather == "rgb8" else None

@@ -245,12 +245,16 @@ int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_r
 /* Same path with everything device-resident and asynchronous, for callers that own the stream
  * and the memory (one process per GPU under torch.distributed, HIP graphs).  d_rgb_out receives
  * only the rows this rank owns, compacted in tile order: rtmi_rank_rows(...)*hsize*3 floats.
- * d_stats (may be NULL) points at RTMI_N_STATS device u64 that are ADDED to.  Allocates nothing:
- * the work memory of the adaptive second pass comes from a per-device pool created with the first
- * scene of the device (4 slots of 2 GB, one per stream that renders).  Work on one stream is
- * ordered, calls on different streams overlap on the GPU; a fifth distinct stream on a device is
- * refused with RTMI_ERR_UNSUPPORTED.  Enqueues a 32 KB memset and one to nine kernels
- * (camera.rs:273-291 first; 290-299 the others).                                                  */
+ * d_stats (may be NULL) points at RTMI_N_STATS device u64 that are ADDED to.  The work memory of
+ * the adaptive second pass comes from a per-device pool of up to 4 slots of 2 GB; a slot belongs
+ * to a stream only while that stream's last call is in flight.  RTMI_WORK_SLOTS_PREALLOC slots
+ * (environment, read when the device's first scene is created; default 2) exist from scene
+ * creation on: while no more streams than that render AT THE SAME TIME the call allocates
+ * nothing; beyond that the first call that needs another slot makes it (one hipMalloc, once).
+ * Any number of streams may render over the life of a process; a fifth stream that renders WHILE
+ * four others have work in flight is refused with RTMI_ERR_UNSUPPORTED.  Work on one stream is
+ * ordered, calls on different streams overlap on the GPU.  Enqueues a 32 KB memset and one to
+ * nine kernels (camera.rs:273-291 first; 290-299 the others).                                     */
 int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera,
                        const rtmi_render_opts *opts, float *d_rgb_out, uint64_t *d_stats,
                        void *hip_stream);
@@ -259,11 +263,17 @@ int rtmi_render_device(const rtmi_scene *scene, const rtmi_camera *camera,
  * one-process-per-GPU form of this is rtmi_render_device with opts->rank/nranks plus an RCCL gather, bench.py).
  * scenes[r] is the same world created on the device that renders share r (rtmi_scene_create with that device
  * current; several or all may live on one device).  Share r = the row tiles t with t % n_scenes == r, tile_rows rows
- * each (0 = 8).  All shares are enqueued before any is waited for; the rows are then gathered to scenes[0]'s device -
- * peer copies over xGMI for shares rendered elsewhere - and put in place there by a small kernel.  d_rgb_out: the
- * WHOLE frame, vsize*hsize*3 floats in memory of scenes[0]'s device.  The image is the single-GPU image bit for bit
- * (RNG keyed by global pixel and sample).  Blocking; allocates and frees its staging buffers; stats_out (may be NULL)
- * = counters summed over the shares, kernel_ms = the call on scenes[0]'s device.                                */
+ * each (0 = 8).  Every share is enqueued on a stream of its own before any is waited for; a share rendered on another
+ * device than scenes[0]'s is copied there by hipMemcpyPeerAsync on that share's stream as soon as ITS kernels are done
+ * (an event; the N - 1 copies run at the same time, each over its own xGMI link) into a staging buffer of its own, and
+ * a small kernel per share puts the rows in place while the other copies are still in flight.  d_rgb_out: the WHOLE
+ * frame, vsize*hsize*3 floats in memory of scenes[0]'s device.  The image is the single-GPU image bit for bit (RNG
+ * keyed by global pixel and sample).  Blocking.  Streams, events, row and staging buffers are made at the first call
+ * for a given (scenes[0], share, frame size) and kept with scenes[0] until it is destroyed: later calls allocate
+ * nothing.  stats_out (may be NULL) = counters summed over the shares; kernel_ms = the WALL span of the whole call on
+ * scenes[0]'s device (first enqueue to last row in place: kernels, peer copies and de-interleaving), not kernel time.
+ * The cross-device path has not run on hardware yet (no multi-GPU box in any session so far): what is verified is the
+ * same code with every share on one device (tests/test_gpu_multi.py) and, when two devices are visible, on two.     */
 int rtmi_render_multi(const rtmi_scene *const *scenes, int32_t n_scenes, const rtmi_camera *camera,
                       const rtmi_render_opts *opts, int32_t tile_rows, float *d_rgb_out,
                       rtmi_stats *stats_out);

@@ -151,8 +151,12 @@ template <typename R> struct DeviceArrays {
 };
 
 // Work-queue memory of the adaptive second pass (rtmi_launch.hpp DWork): a per-device pool of up to WORK_SLOTS buffers.
-// The first is created with the first scene on the device, the others the first time that many streams render at once;
-// all are freed with the device's last scene.  A slot belongs to a stream while work of that stream is in flight on it
+// RTMI_WORK_SLOTS_PREALLOC of them (environment, read when the device's first scene is created; default 2, at most
+// WORK_SLOTS) are created with the first scene on the device - a caller that will render on k streams at once sets it to
+// k and its enqueue path (rtmi_render_device: "asynchronous, allocates nothing") never meets a hipMalloc; a caller that did
+// not reserve enough gets the missing slots the first time that many streams render at once (a one-off stall at that call,
+// and RTMI_ERR_NOMEM there if the device is full - reserve up front, or use rtmi_render_device_noalloc, to rule that out).
+// All are freed with the device's last scene.  A slot belongs to a stream while work of that stream is in flight on it
 // (work on one stream is ordered, so one slot per stream is race-free); after every call an event is recorded on the
 // stream, and a slot whose event has completed may be given to another stream.  A process may therefore use any number
 // of streams over its life, WORK_SLOTS of them rendering at the same time.
@@ -199,8 +203,14 @@ static int pool_acquire(int dev) {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     WorkPool &p = g_pool[dev];
     if (p.refs == 0) {
-        int rc = pool_make_slot(p, 0);
-        if (rc != RTMI_OK) return rc;
+        const long want = std::max(1l, std::min((long)WORK_SLOTS, env_long("RTMI_WORK_SLOTS_PREALLOC", 2)));
+        for (int i = 0; i < (int)want; ++i) {
+            int rc = pool_make_slot(p, i);
+            if (rc != RTMI_OK) { // (none or all: a half-made pool is freed again)
+                for (int k = 0; k < i; ++k) { (void)hipFree(p.buf[k]); (void)hipEventDestroy(p.done[k]); p.buf[k] = nullptr; p.done[k] = nullptr; }
+                return rc;
+            }
+        }
     }
     ++p.refs;
     return RTMI_OK;
@@ -275,9 +285,41 @@ static int static_scratch(int dev, void **out) {
     return RTMI_OK;
 }
 
+// What rtmi_render (host frame out) keeps between calls: the frame on the device, a pinned staging buffer the copy engine
+// writes into, a stream and events.  Made at the first call for a frame size, freed with the scene.
+constexpr int HOST_CHUNKS = 8; // the frame crosses PCIe in this many pieces; a piece is copied on to the caller's memory while the next one is in flight
+struct HostFrameCache {
+    std::mutex m;
+    size_t values = 0;
+    float *d_out = nullptr, *pinned = nullptr;
+    uint64_t *d_stats = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, chunk[HOST_CHUNKS] = {};
+};
+// What rtmi_render_multi keeps with scenes[0]: per device a stream; per share its rows and counters on its device, a
+// staging buffer and a stream on scenes[0]'s device, and two events.  Made at the first call for a set of scenes and a
+// frame size, freed with scenes[0] (or when a call comes with another set / size).
+struct MultiShare {
+    int device = -1;
+    size_t values = 0;
+    float *rows = nullptr, *stage = nullptr;
+    uint64_t *stats = nullptr;
+    hipStream_t gather = nullptr;       // on scenes[0]'s device: waits for the share, copies it over, puts its rows in place
+    hipEvent_t rendered = nullptr, placed = nullptr;
+};
+struct MultiCache {
+    std::mutex m;
+    int hsize = 0, vsize = 0, tile_rows = 0;
+    std::vector<const void *> key;      // the scene handles of the call the cache was made for
+    std::vector<MultiShare> shares;
+    std::vector<std::pair<int, hipStream_t>> render_streams; // one per distinct device
+};
+
 struct rtmi_scene {
     int device = -1;
     bool pooled = false;
+    mutable HostFrameCache host_cache;
+    mutable MultiCache multi_cache;
     DeviceArrays<float> f32;
     DeviceArrays<double> f64;
     DNode *nodes = nullptr;
@@ -1312,6 +1354,28 @@ static int ensure_device(int *dev) {
     return RTMI_OK;
 }
 
+static void host_cache_free(HostFrameCache &c) { // (the scene's device current)
+    (void)hipFree(c.d_out); (void)hipFree(c.d_stats);
+    if (c.pinned) (void)hipHostFree(c.pinned);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    if (c.e0) (void)hipEventDestroy(c.e0);
+    if (c.e1) (void)hipEventDestroy(c.e1);
+    for (hipEvent_t &e : c.chunk) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    c.d_out = nullptr; c.d_stats = nullptr; c.pinned = nullptr; c.stream = nullptr; c.e0 = nullptr; c.e1 = nullptr; c.values = 0;
+}
+static void multi_cache_free(MultiCache &c, int dev0) {
+    for (MultiShare &sh : c.shares) {
+        if (sh.device >= 0) { (void)hipSetDevice(sh.device); (void)hipFree(sh.rows); (void)hipFree(sh.stats); if (sh.rendered) (void)hipEventDestroy(sh.rendered); }
+        (void)hipSetDevice(dev0);
+        (void)hipFree(sh.stage);
+        if (sh.gather) (void)hipStreamDestroy(sh.gather);
+        if (sh.placed) (void)hipEventDestroy(sh.placed);
+    }
+    for (auto &ds : c.render_streams) { (void)hipSetDevice(ds.first); if (ds.second) (void)hipStreamDestroy(ds.second); }
+    c.shares.clear(); c.render_streams.clear(); c.key.clear();
+    c.hsize = c.vsize = c.tile_rows = 0;
+}
+
 extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (!s) return;
     int prev = -1;
@@ -1319,6 +1383,9 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
     (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
     (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->photons); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->pairs); (void)hipFree(s->others); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
+    host_cache_free(s->host_cache);
+    multi_cache_free(s->multi_cache, s->device);
+    (void)hipSetDevice(s->device);
     if (s->pooled) pool_release(s->device);
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     delete s;
@@ -1528,7 +1595,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     int slot = -1;
     std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
     size_t wbytes = work_bytes();
-    if (static_work) {
+    if (static_work && open_ended) { // (a call that cannot reach the second pass - one sample, a cap within the first samples - touches no work memory)
         // no queue may overflow here: a frame (or rank share) is accepted only if each queue can hold every pixel of it
         const size_t cap = f64 ? make_work<double>(static_work, static_bytes).cap : make_work<float>(static_work, static_bytes).cap;
         const size_t pixels = (size_t)rows * (size_t)c->hsize;
@@ -1573,6 +1640,12 @@ extern "C" int rtmi_render_device_timed(const rtmi_scene *scene, const rtmi_came
     int rc = check_camera(camera);
     if (rc != RTMI_OK) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
+    *ms_first_pass = 0; *ms_second_pass = 0;
+    {   // a rank that owns no rows launches nothing and records no event: zero durations, not an error
+        int rank = 0, nranks = 1, tr = 8;
+        if (opts && opts->nranks > 1) { nranks = opts->nranks; rank = opts->rank; tr = norm_tile_rows(opts->tile_rows); }
+        if (rank >= 0 && rank < nranks && rtmi_rank_rows(camera->vsize, rank, nranks, tr) == 0) return RTMI_OK;
+    }
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
 #define TRY_EV(expr)                                                                                              \
@@ -1586,17 +1659,19 @@ extern "C" int rtmi_render_device_timed(const rtmi_scene *scene, const rtmi_came
     if (rc != RTMI_OK) { cleanup(); return rc; }
     TRY_EV(hipEventRecord(ev[2], st));
     TRY_EV(hipEventSynchronize(ev[2]));
-    *ms_first_pass = 0; *ms_second_pass = 0;
-    if (hipEventQuery(ev[1]) == hipSuccess) { // (not recorded when this rank owns no rows)
-        TRY_EV(hipEventElapsedTime(ms_first_pass, ev[0], ev[1]));
-        TRY_EV(hipEventElapsedTime(ms_second_pass, ev[1], ev[2]));
-    }
+    TRY_EV(hipEventElapsedTime(ms_first_pass, ev[0], ev[1]));
+    TRY_EV(hipEventElapsedTime(ms_second_pass, ev[1], ev[2]));
 #undef TRY_EV
     cleanup();
     return RTMI_OK;
 }
 
 // ---- one process, several GPUs: row tiles rendered where the scenes live, rows gathered to the first scene's device ----
+// Every device renders its shares on a stream of its own; share r's rows leave for scenes[0]'s device as soon as THEY are
+// done: a stream per share on that device waits for the share's event, copies the rows over (hipMemcpyPeerAsync: the N - 1
+// copies are in flight together, each on its own xGMI link - what a gather is on this point-to-point fabric; nothing is
+// reduced, so RCCL would add a communicator and nothing else) into the share's own staging buffer and puts them in
+// place with a small kernel while the other copies are still coming.  Nothing is allocated after the first call.
 extern "C" int rtmi_render_multi(const rtmi_scene *const *scenes, int32_t n_scenes, const rtmi_camera *camera, const rtmi_render_opts *opts,
                                  int32_t tile_rows, float *d_rgb_out, rtmi_stats *stats_out) {
     if (!scenes || n_scenes <= 0 || !d_rgb_out) return fail(RTMI_ERR_INVALID, "null scenes or output");
@@ -1608,80 +1683,85 @@ extern "C" int rtmi_render_multi(const rtmi_scene *const *scenes, int32_t n_scen
     HIP_TRY(hipGetDevice(&prev));
     const int N = n_scenes, tr = norm_tile_rows(tile_rows), dev0 = scenes[0]->device;
     const size_t row_values = (size_t)camera->hsize * 3;
-    std::vector<float *> rows((size_t)N, nullptr);   // each rank's compact rows, on its device
-    std::vector<uint64_t *> dstats((size_t)N, nullptr);
-    float *stage = nullptr;                           // on the first device: a remote rank's rows before they are put in place
-    size_t stage_values = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    auto cleanup = [&]() {
-        for (int r = 0; r < N; ++r) {
-            if (rows[(size_t)r] || dstats[(size_t)r]) { (void)hipSetDevice(scenes[r]->device); (void)hipFree(rows[(size_t)r]); (void)hipFree(dstats[(size_t)r]); }
-        }
-        (void)hipSetDevice(dev0);
-        (void)hipFree(stage);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-        (void)hipSetDevice(prev);
-    };
+    MultiCache &mc = scenes[0]->multi_cache;
+    std::lock_guard<std::mutex> lock(mc.m); // (calls that gather to the same scenes[0] take turns)
 #define TRY_MULTI(expr)                                                                                            \
     do {                                                                                                           \
         hipError_t e_ = (expr);                                                                                    \
-        if (e_ != hipSuccess) { cleanup(); return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+        if (e_ != hipSuccess) { (void)hipSetDevice(prev); return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
     } while (0)
+    std::vector<const void *> key((size_t)N);
+    for (int r = 0; r < N; ++r) key[(size_t)r] = scenes[r];
+    if (mc.key != key || mc.hsize != camera->hsize || mc.vsize != camera->vsize || mc.tile_rows != tr) {
+        multi_cache_free(mc, dev0);
+        mc.shares.assign((size_t)N, MultiShare());
+        for (int r = 0; r < N; ++r) {
+            MultiShare &sh = mc.shares[(size_t)r];
+            sh.device = scenes[r]->device;
+            sh.values = (size_t)rtmi_rank_rows(camera->vsize, r, N, tr) * row_values;
+            TRY_MULTI(hipSetDevice(sh.device));
+            bool have = false;
+            for (auto &ds : mc.render_streams) have = have || ds.first == sh.device;
+            if (!have) { hipStream_t st = nullptr; TRY_MULTI(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); mc.render_streams.emplace_back(sh.device, st); }
+            TRY_MULTI(hipMalloc((void **)&sh.stats, RTMI_N_STATS * sizeof(uint64_t)));
+            TRY_MULTI(hipMalloc((void **)&sh.rows, std::max<size_t>(sh.values, 1) * sizeof(float)));
+            TRY_MULTI(hipEventCreateWithFlags(&sh.rendered, hipEventDisableTiming));
+            TRY_MULTI(hipSetDevice(dev0));
+            if (sh.device != dev0) TRY_MULTI(hipMalloc((void **)&sh.stage, std::max<size_t>(sh.values, 1) * sizeof(float)));
+            TRY_MULTI(hipStreamCreateWithFlags(&sh.gather, hipStreamNonBlocking));
+            TRY_MULTI(hipEventCreateWithFlags(&sh.placed, hipEventDisableTiming));
+        }
+        mc.key = key; mc.hsize = camera->hsize; mc.vsize = camera->vsize; mc.tile_rows = tr;
+    }
     rtmi_render_opts o;
     memset(&o, 0, sizeof o);
     if (opts) o = *opts;
     o.nranks = N; o.tile_rows = tr;
-    TRY_MULTI(hipSetDevice(dev0));
-    TRY_MULTI(hipEventCreate(&e0));
-    TRY_MULTI(hipEventCreate(&e1));
-    TRY_MULTI(hipEventRecord(e0, 0));
-    // every rank's kernels are enqueued before any is waited for: the devices render at the same time
+    const auto t0 = std::chrono::steady_clock::now();
+    // every share's kernels are enqueued before any is waited for: the devices render at the same time
     for (int r = 0; r < N; ++r) {
-        const size_t values = (size_t)rtmi_rank_rows(camera->vsize, r, N, tr) * row_values;
-        TRY_MULTI(hipSetDevice(scenes[r]->device));
-        TRY_MULTI(hipMalloc((void **)&dstats[(size_t)r], RTMI_N_STATS * sizeof(uint64_t)));
-        TRY_MULTI(hipMemsetAsync(dstats[(size_t)r], 0, RTMI_N_STATS * sizeof(uint64_t), 0));
-        if (values == 0) continue;
-        TRY_MULTI(hipMalloc((void **)&rows[(size_t)r], values * sizeof(float)));
-        o.rank = r;
-        rc = launch_render(scenes[r], camera, &o, rows[(size_t)r], dstats[(size_t)r], 0);
-        if (rc != RTMI_OK) { cleanup(); return rc; }
-        if (scenes[r]->device != dev0) stage_values = std::max(stage_values, values);
+        MultiShare &sh = mc.shares[(size_t)r];
+        hipStream_t rs = nullptr;
+        for (auto &ds : mc.render_streams) if (ds.first == sh.device) rs = ds.second;
+        TRY_MULTI(hipSetDevice(sh.device));
+        TRY_MULTI(hipMemsetAsync(sh.stats, 0, RTMI_N_STATS * sizeof(uint64_t), rs));
+        if (sh.values) {
+            o.rank = r;
+            rc = launch_render(scenes[r], camera, &o, sh.rows, sh.stats, rs);
+            if (rc != RTMI_OK) { (void)hipSetDevice(prev); return rc; }
+        }
+        TRY_MULTI(hipEventRecord(sh.rendered, rs));
     }
     TRY_MULTI(hipSetDevice(dev0));
-    if (stage_values) TRY_MULTI(hipMalloc((void **)&stage, stage_values * sizeof(float)));
+    for (int r = 0; r < N; ++r) {
+        MultiShare &sh = mc.shares[(size_t)r];
+        TRY_MULTI(hipStreamWaitEvent(sh.gather, sh.rendered, 0));
+        if (sh.values) {
+            const float *src = sh.rows;
+            if (sh.device != dev0) { // over xGMI into this share's staging buffer (the copy engine; no kernel reads remote memory)
+                TRY_MULTI(hipMemcpyPeerAsync(sh.stage, dev0, sh.rows, sh.device, sh.values * sizeof(float), sh.gather));
+                src = sh.stage;
+            }
+            const int grid = (int)std::min<size_t>((sh.values + 255) / 256, 65535);
+            hipLaunchKernelGGL(deinterleave_kernel, dim3(grid), dim3(256), 0, sh.gather, src, d_rgb_out, (long long)sh.values, (int)row_values, tr, r, N);
+            TRY_MULTI(hipGetLastError());
+        }
+        TRY_MULTI(hipEventRecord(sh.placed, sh.gather));
+    }
     rtmi_stats total;
     memset(&total, 0, sizeof total);
     for (int r = 0; r < N; ++r) {
-        const size_t values = (size_t)rtmi_rank_rows(camera->vsize, r, N, tr) * row_values;
-        const int dev = scenes[r]->device;
-        TRY_MULTI(hipSetDevice(dev));
-        TRY_MULTI(hipDeviceSynchronize()); // this rank's rows are complete
+        MultiShare &sh = mc.shares[(size_t)r];
+        TRY_MULTI(hipEventSynchronize(sh.placed)); // (after sh.rendered by stream order: the share's counters are final)
         uint64_t c[RTMI_N_STATS];
-        TRY_MULTI(hipMemcpy(c, dstats[(size_t)r], sizeof c, hipMemcpyDeviceToHost));
+        TRY_MULTI(hipSetDevice(sh.device));
+        TRY_MULTI(hipMemcpy(c, sh.stats, sizeof c, hipMemcpyDeviceToHost));
         for (int k = 0; k < RTMI_N_STATS; ++k) total.counter[k] += c[k];
-        if (values == 0) continue;
-        TRY_MULTI(hipSetDevice(dev0));
-        const float *src = rows[(size_t)r];
-        if (dev != dev0) { // over xGMI into the staging buffer (the copy engine; no kernel reads remote memory)
-            TRY_MULTI(hipMemcpyPeer(stage, dev0, rows[(size_t)r], dev, values * sizeof(float)));
-            src = stage;
-        }
-        const int grid = (int)std::min<size_t>((values + 255) / 256, 65535);
-        hipLaunchKernelGGL(deinterleave_kernel, dim3(grid), dim3(256), 0, 0, src, d_rgb_out, (long long)values, (int)row_values, tr, r, N);
-        TRY_MULTI(hipGetLastError());
-        if (dev != dev0) TRY_MULTI(hipDeviceSynchronize()); // (the staging buffer is reused by the next remote rank)
     }
-    TRY_MULTI(hipSetDevice(dev0));
-    TRY_MULTI(hipEventRecord(e1, 0));
-    TRY_MULTI(hipEventSynchronize(e1));
-    float ms = 0;
-    TRY_MULTI(hipEventElapsedTime(&ms, e0, e1));
-    total.kernel_ms = ms;
+    total.kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); // the wall span of the call, not kernel time
     if (stats_out) *stats_out = total;
 #undef TRY_MULTI
-    cleanup();
+    (void)hipSetDevice(prev);
     return RTMI_OK;
 }
 
@@ -1766,6 +1846,73 @@ extern "C" int rtmi_render_device_noalloc(const rtmi_scene *scene, const rtmi_ca
     return launch_render(scene, camera, opts, d_rgb_out, d_stats, (hipStream_t)hip_stream, work, STATIC_SCRATCH_BYTES);
 }
 
+// Camera::render with a host Canvas out (camera.rs:155-161).  The frame is rendered into a device buffer the scene keeps,
+// then crosses PCIe in HOST_CHUNKS pieces into a pinned staging buffer (asynchronous copies, one event per piece); as each
+// piece lands, host threads copy it on to the caller's (pageable) memory while the next piece is still in flight - the
+// copy engine and the host's memory bandwidth work at the same time instead of one hipMemcpy staging the whole frame
+// through the runtime's own bounce buffers.  Buffers, stream and events are made at the first call for a frame size.
+// A call that finds the scene's buffers in use by another thread takes buffers of its own for the call.
+static int render_to_host(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *o, float *rgb_out, rtmi_stats *stats_out,
+                          HostFrameCache &c) {
+    const size_t n = (size_t)camera->hsize * camera->vsize * 3;
+#define TRY_HOST(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    if (c.values != n) {
+        host_cache_free(c);
+        TRY_HOST(hipMalloc((void **)&c.d_out, n * sizeof(float)));
+        TRY_HOST(hipMalloc((void **)&c.d_stats, RTMI_N_STATS * sizeof(uint64_t)));
+        TRY_HOST(hipHostMalloc((void **)&c.pinned, n * sizeof(float), hipHostMallocDefault));
+        TRY_HOST(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        TRY_HOST(hipEventCreate(&c.e0));
+        TRY_HOST(hipEventCreate(&c.e1));
+        for (hipEvent_t &e : c.chunk) TRY_HOST(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.values = n;
+    }
+    TRY_HOST(hipMemsetAsync(c.d_stats, 0, RTMI_N_STATS * sizeof(uint64_t), c.stream));
+    TRY_HOST(hipEventRecord(c.e0, c.stream));
+    int rc = launch_render(scene, camera, o, c.d_out, c.d_stats, c.stream);
+    if (rc != RTMI_OK) { (void)hipStreamSynchronize(c.stream); return rc; }
+    TRY_HOST(hipEventRecord(c.e1, c.stream));
+    // whole rows per piece
+    const size_t row_values = (size_t)camera->hsize * 3, rows = (size_t)camera->vsize;
+    size_t first[HOST_CHUNKS + 1];
+    for (int k = 0; k <= HOST_CHUNKS; ++k) first[k] = rows * (size_t)k / HOST_CHUNKS * row_values;
+    for (int k = 0; k < HOST_CHUNKS; ++k) {
+        const size_t len = first[k + 1] - first[k];
+        if (len) TRY_HOST(hipMemcpyAsync(c.pinned + first[k], c.d_out + first[k], len * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+        TRY_HOST(hipEventRecord(c.chunk[k], c.stream));
+    }
+    // pinned -> the caller's memory, piece by piece as the events complete, each piece split over a few threads
+    const int n_threads = (int)std::max(1l, std::min(8l, env_long("RTMI_HOST_COPY_THREADS", 4)));
+    hipError_t werr = hipSuccess;
+    for (int k = 0; k < HOST_CHUNKS; ++k) {
+        const hipError_t e = hipEventSynchronize(c.chunk[k]);
+        if (e != hipSuccess) { werr = e; break; }
+        const size_t len = first[k + 1] - first[k];
+        if (len < (size_t)1 << 18 || n_threads == 1) { memcpy(rgb_out + first[k], c.pinned + first[k], len * sizeof(float)); continue; }
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) {
+            const size_t a = first[k] + len * (size_t)t / n_threads, b = first[k] + len * (size_t)(t + 1) / n_threads;
+            pool.emplace_back([=, &c]() { memcpy(rgb_out + a, c.pinned + a, (b - a) * sizeof(float)); });
+        }
+        memcpy(rgb_out + first[k], c.pinned + first[k], (len / n_threads) * sizeof(float));
+        for (auto &th : pool) th.join();
+    }
+    if (werr != hipSuccess) { (void)hipStreamSynchronize(c.stream); return fail(RTMI_ERR_DEVICE, std::string("rtmi_render: ") + hipGetErrorString(werr)); }
+    if (stats_out) {
+        memset(stats_out, 0, sizeof *stats_out);
+        TRY_HOST(hipMemcpy(stats_out->counter, c.d_stats, RTMI_N_STATS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        float ms = 0;
+        TRY_HOST(hipEventElapsedTime(&ms, c.e0, c.e1));
+        stats_out->kernel_ms = ms;
+    }
+#undef TRY_HOST
+    return RTMI_OK;
+}
+
 extern "C" int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts, float *rgb_out, rtmi_stats *stats_out) {
     if (!scene || !rgb_out) return fail(RTMI_ERR_INVALID, "null scene or output");
     int rc = check_camera(camera);
@@ -1774,38 +1921,24 @@ extern "C" int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, c
     memset(&o, 0, sizeof o);
     if (opts) o = *opts;
     o.rank = 0; o.nranks = 1;
-    size_t n = (size_t)camera->hsize * camera->vsize * 3;
-    float *d_out = nullptr;
-    uint64_t *d_stats = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, n * sizeof(float)));
-    rc = RTMI_OK;
-    auto cleanup = [&]() { (void)hipFree(d_out); (void)hipFree(d_stats); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+    int cur_dev = -1;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    if (cur_dev != scene->device)
+        return fail(RTMI_ERR_DEVICE, "the scene lives on device " + std::to_string(scene->device) + " but the current HIP device is " + std::to_string(cur_dev));
+    std::unique_lock<std::mutex> lock(scene->host_cache.m, std::try_to_lock);
+    if (lock.owns_lock()) return render_to_host(scene, camera, &o, rgb_out, stats_out, scene->host_cache);
+    HostFrameCache own; // another thread is rendering this scene to the host right now: buffers of this call's own
+    rc = render_to_host(scene, camera, &o, rgb_out, stats_out, own);
+    host_cache_free(own);
+    return rc;
+}
+
+// (host entry points below: on a HIP error free what the call allocated - `cleanup` of the enclosing function - and fail)
 #define TRY_OR_CLEAN(expr)                                                                      \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) { cleanup(); return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
     } while (0)
-    TRY_OR_CLEAN(hipMalloc((void **)&d_stats, RTMI_N_STATS * sizeof(uint64_t)));
-    TRY_OR_CLEAN(hipMemset(d_stats, 0, RTMI_N_STATS * sizeof(uint64_t)));
-    TRY_OR_CLEAN(hipEventCreate(&e0));
-    TRY_OR_CLEAN(hipEventCreate(&e1));
-    TRY_OR_CLEAN(hipEventRecord(e0, 0));
-    rc = launch_render(scene, camera, &o, d_out, d_stats, 0);
-    if (rc != RTMI_OK) { cleanup(); return rc; }
-    TRY_OR_CLEAN(hipEventRecord(e1, 0));
-    TRY_OR_CLEAN(hipEventSynchronize(e1));
-    TRY_OR_CLEAN(hipMemcpy(rgb_out, d_out, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (stats_out) {
-        memset(stats_out, 0, sizeof *stats_out);
-        TRY_OR_CLEAN(hipMemcpy(stats_out->counter, d_stats, RTMI_N_STATS * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        float ms = 0;
-        TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
-        stats_out->kernel_ms = ms;
-    }
-    cleanup();
-    return RTMI_OK;
-}
 
 extern "C" int rtmi_tonemap_u8_device(const float *d_rgb, uint8_t *d_rgb8, int64_t n_values, void *hip_stream) {
     if (!d_rgb || !d_rgb8 || n_values < 0) return fail(RTMI_ERR_INVALID, "bad tonemap arguments");

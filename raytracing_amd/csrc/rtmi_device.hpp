@@ -1560,6 +1560,9 @@ __device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &
     open.best = NONE; open.other = NONE; open.best_t = 0; open.other_t = 0; open.hit_parity = 0;
     Hit<R> dummy = {Lim<R>::inf(), NONE, 0};
     traverse<R, MODE_COLLECT, TREE>(sc, ray, origin_leaf, origin_side, dummy, h.t, h.leaf, h.ord, open, st);
+    if ((open.best != NONE && open.best >= sc.n_leaves) || (open.other != NONE && open.other >= sc.n_leaves)) { // (never: see color_at)
+        st.c[RTMI_STAT_OVERFLOW] = 1; open.best = NONE; open.other = NONE;
+    }
     c.n1 = open.best != NONE ? leaf_ior<R, TREE>(sc, open.best) : (R)1;
     if (open.hit_parity & 1u) c.n2 = open.other != NONE ? leaf_ior<R, TREE>(sc, open.other) : (R)1;
     else c.n2 = leaf_ior<R, TREE>(sc, h.leaf);
@@ -1789,6 +1792,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
         Open<R> unused;
         traverse<R, MODE_CLOSEST, TREE>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
         bool spawned = false;
+        if (h.leaf != NONE && h.leaf >= sc.n_leaves) { st.c[RTMI_STAT_OVERFLOW] = 1; h.leaf = NONE; } // (never: a leaf index must not become an address unchecked)
         if (h.leaf != NONE) {
             Comps<R> c;
             uint32_t kind, material;
@@ -2054,6 +2058,7 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
         Open<R> unused;
         traverse<R, MODE_CLOSEST, true>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
         rays++;
+        if (h.leaf != NONE && h.leaf >= sc.n_leaves) h.leaf = NONE; // (never: see color_at)
         if (h.leaf == NONE) { alive = false; continue; }
         Comps<R> c;
         uint32_t lkind, material;
@@ -2074,7 +2079,7 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
             spec *= r; trans *= (R)1 - r;
         }
         const R p_absorb = (R)1 - pd_avg - spec - trans;
-        if (!(p_absorb >= (R)0)) { // materials.rs:443-445 panics: the call fails and names the leaf
+        if (!(p_absorb >= (R)0) || p_absorb > (R)1) { // materials.rs:443-445 asserts 0 <= p_absorb <= 1 and panics: the call fails and names the leaf
             if constexpr (!STORE) counters[PT_BAD_LEAF] = (unsigned long long)sc.leaf_orig[h.leaf] + 1ull;
             alive = false;
             continue;

@@ -151,6 +151,66 @@ def lights_gallery(h=300, v=150, deterministic=False, random_lights=True):
     return w, _camera(h, v, (0.5, 4.5, -9), (0, 1, 0), se=2e-2, min_samples=4, deterministic=deterministic)
 
 
+def crowd(h=300, v=150, deterministic=False):
+    """Not a reference example: a FLAT world (World::objects all primitives, world.rs:145-156 brute force) that is larger than
+    every table the flat-scene kernels stage in LDS - 46 top-level primitives of every kind (the block holds 16), 24
+    materials (16), 9 patterned leaves of all four pattern kinds, some of them past the 16th leaf (4 folded pattern slots)
+    and 6 lights (4) - so that the paths a small scene never takes (leaves from global records, materials, lights and
+    patterns from global memory, a non-shadowing leaf among the pairs) are compared with the oracle too.  Positions and
+    sizes come from a fixed Philox stream; nothing touches anything else exactly (no ties in t)."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(4)
+    w.add_light(rt.AmbientLight(rt.color(0.06, 0.06, 0.06)))
+    w.add_light(rt.PointLight(rt.point(-8, 9, -7), rt.color(0.3, 0.3, 0.3)))
+    w.add_light(rt.PointLight(rt.point(7, 8, -5), rt.color(0.25, 0.22, 0.2)))
+    w.add_light(rt.PointLight(rt.point(0, 12, 4), rt.color(0.2, 0.2, 0.25)))
+    w.add_light(rt.RealisticPointLight(rt.point(-2, 6, -6), rt.color(25, 25, 20)))
+    w.add_light(rt.PointLight(rt.point(3, 3, -9), rt.color(0.15, 0.15, 0.15)))
+    u = lambda i, k: _philox_uniform(0xC20D, i, k)
+    pats = [lambda a, b: rt.stripe_pattern(a, b).with_transform(rt.translation(0.07, 0, 0) * rt.scaling(0.3, 1, 1)),
+            lambda a, b: rt.gradient_pattern(a, b).with_transform(rt.translation(-1, 0, 0) * rt.scaling(2, 1, 1)),
+            lambda a, b: rt.ring_pattern(a, b).with_transform(rt.scaling(0.23, 1, 0.23)),
+            lambda a, b: rt.checkers_pattern(a, b).with_transform(rt.translation(0.011, 0.013, 0.017) * rt.scaling(0.41, 0.41, 0.41))]
+    mats = []
+    for m in range(24):
+        col = rt.color(0.25 + 0.7 * u(m, 0), 0.25 + 0.7 * u(m, 1), 0.25 + 0.7 * u(m, 2))
+        ph = rt.Phong.default().with_color(col).with_diffuse(0.6 + 0.3 * u(m, 3)).with_specular(0.5 * u(m, 4)).with_shininess(20.0 + 200.0 * u(m, 5))
+        if m % 8 == 3:
+            ph = ph.with_reflective(0.35)
+        if m == 13:
+            ph = rt.Phong.default().with_rgb(0.1, 0.1, 0.1).with_diffuse(0.2).with_transparency(0.85).with_reflective(0.5).with_refractive_index(1.45)
+        if m in (0, 2, 5, 9, 11, 14, 17, 20, 22):
+            ph = ph.with_pattern(pats[m % 4](col, rt.color(0.95 - 0.5 * u(m, 6), 0.9 - 0.5 * u(m, 7), 0.85 - 0.5 * u(m, 8))))
+        mats.append(ph)
+    w.add_item(rt.plane().with_material(mats[0]))                                                                      # patterned, leaf 0
+    w.add_item(rt.plane().with_transform(rt.translation(0, 0, 14) * rt.rotation_x(PI / 2.0)).with_material(mats[1]))
+    k = 2
+    for i in range(44):
+        x, z = -7.0 + 14.0 * u(100 + i, 0), -3.0 + 12.0 * u(100 + i, 1)
+        r = 0.25 + 0.45 * u(100 + i, 2)
+        y = r + 2.2 * u(100 + i, 3) * (1 if i % 3 else 0)
+        mat = mats[k % 24]
+        kind = i % 6
+        if kind == 0:
+            item = rt.sphere().with_transform(rt.translation(x, y, z) * rt.scaling(r, r, r))                           # LEAF_QUICK sphere
+        elif kind == 1:
+            item = rt.sphere().with_transform(rt.translation(x, y, z) * rt.rotation_z(0.4) * rt.scaling(r, 0.6 * r, 1.3 * r))  # an ellipsoid: global record
+        elif kind == 2:
+            item = rt.cube().with_transform(rt.translation(x, y, z) * rt.rotation_y(3.0 * u(100 + i, 4)) * rt.scaling(r, r, r))
+        elif kind == 3:
+            item = rt.cylinder(-1.0, 1.0, True).with_transform(rt.translation(x, y, z) * rt.scaling(0.7 * r, r, 0.7 * r))
+        elif kind == 4:
+            item = rt.cone(-1.0, 0.0, True).with_transform(rt.translation(x, y + r, z) * rt.scaling(r, 2 * r, r))
+        else:
+            item = rt.triangle(rt.point(x - r, y - r, z), rt.point(x + r, y - r, z + 0.3 * r), rt.point(x, y + r, z - 0.2 * r))
+        item = item.with_material(mat)
+        if i in (6, 30):
+            item = item.with_cast_shadow(False)                                                                        # (a quick sphere and a late leaf that cast no shadow)
+        w.add_item(item)
+        k += 1
+    return w, _camera(h, v, (0.5, 5.5, -11), (0, 1.2, 2), se=2e-2, min_samples=4, deterministic=deterministic)
+
+
 def yard(h=300, v=150, deterministic=False, bounded=True):
     """Not a reference example: one Group (or, `bounded`, the BoundingGroup tree build_bounding_tree makes of it) that holds
     every kind of item a subtree can - spheres, cubes, closed and open finite cylinders, cones, flat and smooth triangles, a
@@ -213,7 +273,7 @@ def yard(h=300, v=150, deterministic=False, bounded=True):
 
 
 def photon_room(h=300, v=150, deterministic=False, direct=True):
-    """Not a reference example (examples/photon-map.rs traces 75 M photons, which this library does not do): a floor, a back
+    """Not a reference example (examples/photon-map.rs is `photon_box` below): a floor, a back
     wall, a matt sphere, a mirror sphere and a glass sphere under one point light, to which a test attaches a photon map
     (World.set_photon_arrays) so that the gather of Phong::shade_hit (materials.rs:376-384) runs on primary, reflected and
     refracted hits.  `direct` False: World::enable_direct_illumination(false), the map is all the light there is."""
@@ -540,7 +600,7 @@ def photon_box_with_map(h=600, v=600, deterministic=False, n_photons=2_000_000, 
     return w, cam
 
 
-EXTRA_SCENES = {"photons": photon_room_with_map, "yard": yard, "photonbox": photon_box_with_map}  # (bench.py --scene takes these too; not BASELINE configurations)
+EXTRA_SCENES = {"photons": photon_room_with_map, "yard": yard, "photonbox": photon_box_with_map, "crowd": crowd}  # (bench.py --scene takes these too; not BASELINE configurations)
 
 BASELINE_SCENES = {
     "ch07": chapter07,

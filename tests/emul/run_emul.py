@@ -31,8 +31,9 @@ def photon_room(h, v, **kw):
     return world, cam
 
 
-EXTRA = {"gallery": scenes.lights_gallery, "yard": scenes.yard, "yard-group": scenes.yard, "photons": photon_room, "photons-only": photon_room}
-for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {}),
+EXTRA = {"gallery": scenes.lights_gallery, "yard": scenes.yard, "yard-group": scenes.yard, "photons": photon_room, "photons-only": photon_room,
+         "crowd": scenes.crowd}
+for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {}), ("crowd", {}),
                  ("yard", {}), ("yard-group", {"bounded": False}), ("photons", {}), ("photons-only", {"direct": False})]:
     world, cam = (EXTRA[name] if name in EXTRA else scenes.BASELINE_SCENES[name])(32, 16, **kw)
     f = world.flatten()
@@ -65,4 +66,30 @@ for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof
     sc.close()
     print("%-7s rays %d  f64 mismatches vs oracle %d  f32 same leaf %.2f %%  f32 colour within 4e-3 and same n1/n2 %.2f %%" % (name, n, bad, 100.0 * same32 / n, 100.0 * col32 / n), flush=True)
     assert bad == 0 and same32 >= 0.995 * n and col32 >= 0.98 * n
+# The host side of rtmi_render (cached device frame, pinned staging, pieces copied on by threads) and of rtmi_render_multi
+# (per-share buffers, streams and events kept with scenes[0]) under ASan.  The render kernels themselves are not emulated
+# (their launcher is a no-op here), so only memory handling is checked: sizes, reuse across calls, a change of frame
+# size, several "devices" worth of shares, release at scene destruction.
+class HostBuffer:
+    def __init__(self, shape):
+        self.a = np.zeros(shape, dtype=np.float32)
+
+    def data_ptr(self):
+        return self.a.ctypes.data
+
+
+world, cam = scenes.chapter11a(64, 40)
+world2, cam2 = scenes.chapter11a(96, 56)
+sc = abi.Scene(world)
+for c in (cam, cam, cam2, cam):
+    img, st = abi.render_host(sc, c)
+    assert img.shape == (c.vsize(), c.hsize(), 3)
+replicas = [abi.Scene(world) for _ in range(3)]
+for c, n in ((cam, 3), (cam, 3), (cam2, 2), (cam, 1)):
+    out = HostBuffer((c.vsize(), c.hsize(), 3))
+    abi.render_multi(replicas[:n], c, abi.make_opts(), out, tile_rows=8)
+for r in replicas:
+    r.close()
+sc.close()
+print("host paths of rtmi_render / rtmi_render_multi clean")
 print("emulation run clean")

@@ -1,5 +1,6 @@
-"""Photon maps for the tests.  Tracing photons (World::compute_photon_map, world.rs:186-273) is not part of the library; the
-gather is (materials.rs:376-384).  So the tests make a map themselves: photons sent from a point in seeded random directions and
+"""Photon maps for the tests of the gather (materials.rs:376-384).  The library traces photons too (rtmi_trace_photons, the tracing
+half of World::compute_photon_map, world.rs:186-273: tests/test_gpu_photon_trace.py); the gather's tests do not depend on it and
+make a map themselves: photons sent from a point in seeded random directions and
 stored where the ORACLE says they first hit (direction = minus the direction of travel, power = colour / n, as emit_photon + store +
 scale_power leave a direct photon, photon_map.rs:140-142 and world.rs:201), plus a seeded scatter of them around, so that estimates see photons from
 all sides.  Both the oracle and the device then get the same array."""

@@ -125,6 +125,44 @@ def test_deterministic_frame_f32_vs_f64_and_oracle_rows():
     assert dd.max() <= 1, int(dd.max())
 
 
+@pytest.mark.parametrize("precision", [1, 0], ids=["f64", "f32"])
+def test_adaptive_frame_rows_against_the_oracle(precision):
+    """The headline workload itself - chapter-11a, 3840x2160, adaptive as shipped - against the oracle on 136 of its rows:
+    17 row tiles (8 rows each, spread over the frame) rendered as rank shares, which gives the device's sample count for
+    exactly those rows (a share's pixels are the frame's, bit for bit: the test above), and the oracle on the same rows
+    with the same seed.  Bars: f64 PSNR >= 60 dB and sample counts within 2e-4; f32 PSNR >= 35 dB, counts within 5 %."""
+    import torch
+    world, cam = scenes.chapter11a(H, V)
+    n_tiles = V // 8
+    tiles_ = [7 + 16 * j for j in range(17)]  # (every row the oracle renders with stride 128 from row 56 + k on)
+    sc = abi.Scene(world)
+    got = np.zeros((len(tiles_), 8, H, 3), dtype=np.float64)
+    samples = 0
+    for j, t in enumerate(tiles_):
+        buf = torch.zeros((8, H, 3), dtype=torch.float32, device="cuda")
+        stats = torch.zeros(abi.N_STATS, dtype=torch.int64, device="cuda")
+        abi.render_device(sc, cam, abi.make_opts(precision=precision, rank=t, nranks=n_tiles, tile_rows=8), buf, stats, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got[j] = buf.cpu().numpy()
+        st = {k: int(x) for k, x in zip(abi.STAT_NAMES, stats.cpu().tolist())}
+        assert st["overflow"] == 0
+        samples += st["samples"]
+    sc.close()
+    want = np.zeros_like(got)
+    ref_samples = 0
+    for k in range(8):  # rows 8 * (7 + 16 j) + k, j = 0 .. 16: one arithmetic progression per k
+        ref, rst = orc.render(world, cam, abi.make_opts(), n_threads=16, row_stride=8 * 16, row_offset=8 * 7 + k)
+        for j, t in enumerate(tiles_):
+            want[j, k] = ref[8 * t + k]
+        ref_samples += rst["samples"]
+    mse = float(np.mean((np.clip(got, 0, 1) - np.clip(want, 0, 1)) ** 2))
+    p = 99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse)
+    rel = abs(samples - ref_samples) / ref_samples
+    print("adaptive rows: PSNR %.1f dB, samples %d oracle %d (rel %.2e)" % (p, samples, ref_samples, rel))
+    assert p >= (60.0 if precision == 1 else 35.0), p
+    assert rel <= (2e-4 if precision == 1 else 5e-2), rel
+
+
 def test_rgb8_conversion_of_the_whole_frame():
     import torch
     world, cam = scenes.chapter07(H, V, deterministic=True)

@@ -1,6 +1,6 @@
 """GPU parity of the photon-map gather in Phong::shade_hit (materials.rs:376-384; PhotonMap::from_vec and find_nearest,
-photon_map.rs:230-364) against the oracle, through the C ABI.  The map itself is a fixture (tests/photon_cases.py): tracing
-photons is not part of the library.
+photon_map.rs:230-364) against the oracle, through the C ABI.  The map itself is a fixture (tests/photon_cases.py) so that the gather is
+tested on its own; the library's own tracing of photons (rtmi_trace_photons) has tests/test_gpu_photon_trace.py.
 
 Bars: f64 validation mode - colours of random rays within 1e-9 of the oracle's (the same kd-tree, the same photons found, the
 same fold), every pixel of a frame within 1/255 and equal ray counts; f32 - >= 99.8 % of pixels within 1/255 (near-ties between
