@@ -419,6 +419,13 @@ struct Stats {
 #define CYC_END(st, i, v)
 #endif
 
+// -DRTMI_SKIP=<bits> (diagnostic builds only: the IMAGE IS WRONG): a stage is left out so that an A/B run against the product
+// build shows what the stage costs on a whole frame (the subtractive twin of the RTMI_CYCLES probes; tools/skip_ab.sh).
+//   1 pattern lookups   2 Phong::lighting   4 the work counters   8 the n1 / n2 container query   16 shadow queries
+#ifndef RTMI_SKIP
+#define RTMI_SKIP 0
+#endif
+
 // Algorithmic FLOP prices per event (mul/add/sub/div/sqrt/exp2/log2 = 1, FMA = 2, compares = 0),
 // derived from the cited reference lines.  They price the REFERENCE's arithmetic, not this kernel's.
 constexpr uint32_t F_XFORM = 33;       // ray -> object space (ray.rs:30-35)
@@ -957,6 +964,57 @@ __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<f
             bt = c;
         }
     };
+    if (MODE == MODE_COLLECT) {
+        // The container query (ray.rs:111-140) asks of every leaf whether an ODD number of its roots lies in front of the hit
+        // (the ray is inside it there) and, if so, where it went in.  For a sphere that is "the hit point lies inside"
+        // (t0 < T <= t1), for a plane "the hit point lies beyond it along the ray" (t < T, behind the origin included:
+        // (n . P + w) and n . d have the same sign) - a few packed operations per pair and no root.  Only a leaf that IS
+        // open (the glass sphere around the bubble, the sphere the ray is leaving) goes on to its roots and the
+        // reference's rule on them (apply_roots), which also orders the open leaves by where they were entered.
+        const V3<float> P = ray.o + ray.d * t_limit;
+        const f2 px = splat2(P.x), py = splat2(P.y), pz = splat2(P.z);
+        auto sphere_roots = [&](uint32_t id, float cx, float cy, float cz, float r2) {
+            const V3<float> oc = ray.o - mk<float>(cx, cy, cz);
+            const float k = dot(ray.d, oc) * inv_a;
+            const V3<float> l = oc - ray.d * k;
+            const float x = (r2 - dot(l, l)) * inv_a;
+            if (x < 0.0f) return;
+            const float s = sqrt_(x);
+            float t[4] = {-k - s, s - k, 0.0f, 0.0f};
+            if (origin_leaf == id) { if (abs_(t[1]) < abs_(t[0])) t[1] = -max_(abs_(t[1]), 1e-30f); else t[0] = -max_(abs_(t[0]), 1e-30f); }
+            apply_roots<float, MODE_COLLECT>(id, 2, t, best, t_limit, hit_leaf, hit_ord, open);
+        };
+        for (uint32_t p = 0; p < n_sph; ++p) {
+            const uint32_t *r = tab + p * (uint32_t)PAIR_DW;
+            const f2 cx = mk2(u2f_(r[0]), u2f_(r[1])), cy = mk2(u2f_(r[2]), u2f_(r[3])), cz = mk2(u2f_(r[4]), u2f_(r[5])), r2 = mk2(u2f_(r[6]), u2f_(r[7]));
+            const uint32_t id0 = r[8], id1 = r[9];
+            const f2 ex = px - cx, ey = py - cy, ez = pz - cz;
+            const f2 q = r2 - (ex * ex + ey * ey + ez * ez);
+            const bool hit0 = id0 == hit_leaf, hit1 = id1 == hit_leaf;
+            if (hit0 || hit1) open.hit_parity = hit_ord; // (a sphere's roots in front of its own hit: the number of the hit root)
+            if (hit0 ? (hit_ord & 1u) != 0u : q.x > 0.0f) sphere_roots(id0, cx.x, cy.x, cz.x, r2.x);
+            if (hit1 ? (hit_ord & 1u) != 0u : q.y > 0.0f) sphere_roots(id1, cx.y, cy.y, cz.y, r2.y);
+        }
+        for (uint32_t p = 0; p < n_pl; ++p) {
+            const uint32_t *r = tab + (sph_all + p) * (uint32_t)PAIR_DW;
+            const f2 nx = mk2(u2f_(r[0]), u2f_(r[1])), ny = mk2(u2f_(r[2]), u2f_(r[3])), nz = mk2(u2f_(r[4]), u2f_(r[5])), w = mk2(u2f_(r[6]), u2f_(r[7]));
+            const uint32_t id0 = r[8], id1 = r[9];
+            const f2 ddy = nx * dx + ny * dy + nz * dz, fp = nx * px + ny * py + nz * pz + w, side = fp * ddy;
+            if (id0 == hit_leaf || id1 == hit_leaf) open.hit_parity = 0u; // (a plane's one root is the hit itself)
+            const bool o0 = id0 != hit_leaf && side.x > 0.0f && !(abs_(ddy.x) < (float)RTMI_EPSILON);
+            const bool o1 = id1 != hit_leaf && side.y > 0.0f && !(abs_(ddy.y) < (float)RTMI_EPSILON);
+            if (o0 || o1) {
+                const f2 ooy = nx * ox + ny * oy + nz * oz + w;
+                if (o0) { float t[4] = {-ooy.x * rcp_(ddy.x), 0.0f, 0.0f, 0.0f}; if (origin_leaf == id0) t[0] = -max_(abs_(t[0]), 1e-30f);
+                          apply_roots<float, MODE_COLLECT>(id0, 1, t, best, t_limit, hit_leaf, hit_ord, open); }
+                if (o1) { float t[4] = {-ooy.y * rcp_(ddy.y), 0.0f, 0.0f, 0.0f}; if (origin_leaf == id1) t[0] = -max_(abs_(t[0]), 1e-30f);
+                          apply_roots<float, MODE_COLLECT>(id1, 1, t, best, t_limit, hit_leaf, hit_ord, open); }
+            }
+        }
+        st.c[RTMI_STAT_LEAF_TESTS] += real_sph + real_pl;
+        st.flops += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE); // (priced as the reference's tests of these leaves; hits are not told apart here)
+        return;
+    }
     for (uint32_t p = 0; p < n_sph; ++p) { // sphere.rs:47-63 in world space, roots as closest approach -+ half chord
         const uint32_t *r = tab + p * (uint32_t)PAIR_DW;
         const f2 cx = mk2(u2f_(r[0]), u2f_(r[1])), cy = mk2(u2f_(r[2]), u2f_(r[3])), cz = mk2(u2f_(r[4]), u2f_(r[5])), r2 = mk2(u2f_(r[6]), u2f_(r[7]));
@@ -1520,7 +1578,9 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
 // a material / the refractive index of a leaf's material: from the LDS block where it holds them
 template <typename R, bool TREE> __device__ __forceinline__ DMaterial<R> load_material(const DScene<R> &sc, uint32_t id) {
     if constexpr (staged_v<R, TREE>) {
-        if (id < sc.n_lds_materials) return *reinterpret_cast<const DMaterial<float> *>(lds_scene() + LDS_MATS_AT + id * (uint32_t)MAT_DW);
+        // (n_lds_materials is all of them or none: a wave-uniform choice between an LDS read and a global load - a per-lane
+        // choice would make every access a flat load through both paths)
+        if (sc.n_lds_materials != 0u) return *reinterpret_cast<const DMaterial<float> *>(lds_scene() + LDS_MATS_AT + min(id, (uint32_t)LDS_MATS - 1u) * (uint32_t)MAT_DW);
     }
     return sc.materials[id];
 }
@@ -1532,7 +1592,7 @@ template <typename R, bool TREE> __device__ __forceinline__ R leaf_ior(const DSc
     }
     if (!have) id = sc.leaves[leaf].material;
     if constexpr (staged_v<R, TREE>) {
-        if (id < sc.n_lds_materials) return u2f_(lds_scene()[LDS_MATS_AT + id * (uint32_t)MAT_DW + 9u]); // DMaterial::ior
+        if (sc.n_lds_materials != 0u) return u2f_(lds_scene()[LDS_MATS_AT + min(id, (uint32_t)LDS_MATS - 1u) * (uint32_t)MAT_DW + 9u]); // DMaterial::ior
     }
     return sc.materials[id].ior;
 }
@@ -1637,6 +1697,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
     if (in.kind == IL_OMNI) return false;
     if (in.kind == IL_NOLIGHT) return true;
     st.c[RTMI_STAT_SHADOW]++;
+    if (RTMI_SKIP & 16) return false;
     Ray<R> sray = {p, in.direction};
     V3<R> to_light = in.origin - p;
     R dist = sqrt_(dot(to_light, to_light));
@@ -1803,7 +1864,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
             // Phong::color_at (materials.rs:239-244): patterns are looked up at comps.point
             V3<R> surface_color = ld3(m.color);
             st.flops += F_PREPARE + (((kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) ? F_SMOOTH_NORMAL : 0u) + F_COMBINE;
-            if (m.pattern >= 0) {
+            if (m.pattern >= 0 && !(RTMI_SKIP & 1)) {
                 bool done = false;
                 if constexpr (staged_v<R, TREE>) {
                     const uint32_t slot = h.leaf < sc.n_quick ? lds_scene()[h.leaf * (uint32_t)QUICK_DW + 2u] : NONE;
@@ -1839,6 +1900,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                 bool in_shadow = is_shadowed<R, TREE>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
                 st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
                 CYC3_BEGIN(c_light);
+                if (RTMI_SKIP & 2) surface = surface + surface_color * (in_shadow ? (R)0 : (R)0.5); else
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
                 CYC3_END(st, 2, c_light);
             }
@@ -1848,7 +1910,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
             bool want_n = first_comps && first;
             bool do_refl = !(m.reflective == (R)0) && remaining > 0;   // materials.rs:297
             bool do_refr = !(m.transparency == (R)0) && remaining > 0; // materials.rs:316
-            if (do_refr || want_n) collect_n1n2<R, TREE>(sc, ray, origin_leaf, origin_side, h, c, st);
+            if ((do_refr || want_n) && !(RTMI_SKIP & 8)) collect_n1n2<R, TREE>(sc, ray, origin_leaf, origin_side, h, c, st);
             CYC4_BEGIN(c_spawn);
             if (first) {
                 if (first_hit) *first_hit = h;

@@ -43,6 +43,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // (second: the kernel belongs to the second pass, its FLOPs are reported in RTMI_STAT_FLOPS_SECOND as well)
 __device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long *__restrict__ stats, bool second = false) {
     if (!stats) return;
+    if (RTMI_SKIP & 4) return; // (diagnostic build: with nobody reading them, the compiler drops the counters' arithmetic)
 #ifdef RTMI_CYCLES
     {
         const int slot[4] = {RTMI_STAT_AABB_TESTS, RTMI_STAT_LEAF_TESTS, RTMI_STAT_NODE_VISITS, RTMI_STAT_FLOPS};
