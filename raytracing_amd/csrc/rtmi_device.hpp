@@ -387,13 +387,70 @@ template <typename R> __device__ __forceinline__ R rng_next(Rng &g) {
     return (R)(v >> 8) * (R)(1.0 / 16777216.0);
 }
 
+// The work counters of one lane.  Two homes (the choice is a constant of the kernel that owns the object, so every test
+// of `in_lds` folds away once the callees are inlined):
+//   registers  c[]: the trace / photon kernels, the second pass's per-wave totals;
+//   LDS        one column of the wave's counter block ([slot][lane], stats_block): the sampling loops of the render
+//              kernels.  Ten counters that live in registers through every traversal, shading and spawn are what the
+//              register allocator pays for with spills (measured on the headline frame: leaving the counters out makes the
+//              first pass 15 % faster, and their arithmetic is a third of that); an update in LDS is one ds_add_u32
+//              with no result - no vector ALU slot, no register.
+// A sample's FLOPs go to `fl` (32 bits: one full-rate addition with a literal) and from there to `flops` when the sample ends.
+constexpr int STAT_SLOTS_FLAT = 7, STAT_SLOTS_TREE = 6, STAT_SLOTS_MAX = 10; // (slots in order of how seldom they count: a tree kernel keeps the per-step ones in registers)
+__device__ __forceinline__ constexpr int stat_slot(int i) {
+    return i == RTMI_STAT_PRIMARY ? 0 : i == RTMI_STAT_REFLECTION ? 1 : i == RTMI_STAT_REFRACTION ? 2 : i == RTMI_STAT_SHADOW ? 3 : i == RTMI_STAT_SAMPLES ? 4
+         : i == RTMI_STAT_OVERFLOW ? 5 : i == RTMI_STAT_LEAF_TESTS ? 6 : i == RTMI_STAT_NODE_VISITS ? 7 : i == RTMI_STAT_AABB_TESTS ? 8 : i == RTMI_STAT_DISCARDED ? 9 : 99;
+}
+__device__ __forceinline__ void lds_add(uint32_t *p, uint32_t v) {
+#ifdef RTMI_HOST_EMUL
+    *p += v;
+#else
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); // (result unused: ds_add_u32)
+#endif
+}
 struct Stats {
     uint32_t c[RTMI_N_STATS]; // c[RTMI_STAT_FLOPS] is unused: flops are summed in 64 bits below
+    uint32_t fl;              // the FLOPs of the sample (photon, probe ray) in hand (stats_sample_end)
     unsigned long long flops;
+    uint32_t *lds;            // this lane's column of the wave's counter block, when in_lds
+    int n_slots;              // slots of that block (counters beyond it stay in c[])
+    bool in_lds;
 #ifdef RTMI_CYCLES
     unsigned long long cyc[4]; // shader-clock cycles: 0 the tree walk (packet_scene), 1 csg_root's leaf loop, 2 its sort + filter, 3 the whole kernel
 #endif
+    __device__ __forceinline__ void add(int i, uint32_t v) {
+        if (in_lds && stat_slot(i) < n_slots) lds_add(lds + stat_slot(i) * 64, v);
+        else c[i] += v;
+    }
+    __device__ __forceinline__ void inc(int i) { add(i, 1u); }
+    __device__ __forceinline__ void flag(int i) { // (RTMI_STAT_OVERFLOW: "happened", never a count that matters)
+        if (in_lds && stat_slot(i) < n_slots) lds[stat_slot(i) * 64] = 1u;
+        else c[i] = 1u;
+    }
+    __device__ __forceinline__ uint32_t get(int i) const { return (in_lds && stat_slot(i) < n_slots) ? lds[stat_slot(i) * 64] + c[i] : c[i]; }
+    // registers as the home
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < RTMI_N_STATS; ++i) c[i] = 0;
+        fl = 0; flops = 0; lds = nullptr; n_slots = 0; in_lds = false;
+#ifdef RTMI_CYCLES
+        cyc[0] = cyc[1] = cyc[2] = cyc[3] = 0;
+#endif
+    }
+    // LDS as the home: `block` = the wave's [n][64] block, zeroed here (this lane's column)
+    __device__ __forceinline__ void zero_in_lds(uint32_t *block, int n, int lane) {
+        zero();
+        lds = block + lane; n_slots = n; in_lds = true;
+#pragma unroll
+        for (int k = 0; k < STAT_SLOTS_MAX; ++k)
+            if (k < n) lds[k * 64] = 0u;
+    }
 };
+template <bool TREE> __device__ __forceinline__ uint32_t *stats_block() { // (one wave per workgroup)
+    __shared__ uint32_t s_stats[TREE ? STAT_SLOTS_TREE : STAT_SLOTS_FLAT][64];
+    return &s_stats[0][0];
+}
+__device__ __forceinline__ void stats_sample_end(Stats &st) { st.flops += st.fl; st.fl = 0; }
 // -DRTMI_CYCLES=1 or 2 (diagnostic builds, tools/cycles.py): where a wave's time goes, summed per wave into the counters
 // aabb_tests, leaf_tests, node_visits and flops INSTEAD of what those normally count.  1: the tree walk and its CSG parts;
 // 2: the three kinds of intersection query (closest hit, shadow, containers).
@@ -651,8 +708,8 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, uint32_t gkind, con
         V3<R> o = xf_point(g.inv, ray.o), d = xf_vector(g.inv, ray.d); // ray.rs:30-35 (direction not renormalised)
         n = local_intersect(g, gkind, tris, o, d, t, u, v, fl, det);
     }
-    st.c[RTMI_STAT_LEAF_TESTS]++;
-    st.flops += F_XFORM + fl;
+    st.inc(RTMI_STAT_LEAF_TESTS);
+    st.fl += F_XFORM + fl;
     if (is_origin && n > 0) {
         int k = 0;
         R best = abs_(t[0]);
@@ -805,7 +862,7 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
                         if (k == 0 || t[i] < first_t) { first_t = t[i]; first_i = k; first_id = id; }
                         buf.put(k, t[i], id);
                         ++k;
-                    } else st.c[RTMI_STAT_OVERFLOW] = 1;
+                    } else st.flag(RTMI_STAT_OVERFLOW);
                 }
             }
         }
@@ -1011,8 +1068,8 @@ __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<f
                           apply_roots<float, MODE_COLLECT>(id1, 1, t, best, t_limit, hit_leaf, hit_ord, open); }
             }
         }
-        st.c[RTMI_STAT_LEAF_TESTS] += real_sph + real_pl;
-        st.flops += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE); // (priced as the reference's tests of these leaves; hits are not told apart here)
+        st.add(RTMI_STAT_LEAF_TESTS, real_sph + real_pl);
+        st.fl += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE); // (priced as the reference's tests of these leaves; hits are not told apart here)
         return;
     }
     for (uint32_t p = 0; p < n_sph; ++p) { // sphere.rs:47-63 in world space, roots as closest approach -+ half chord
@@ -1051,8 +1108,8 @@ __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<f
         if (MODE != MODE_COLLECT || h0) take(id0, t0, 0.0f, false);
         if (MODE != MODE_COLLECT || h1) take(id1, t1, 0.0f, false);
     }
-    st.c[RTMI_STAT_LEAF_TESTS] += real_sph + real_pl;
-    st.flops += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE) + sphere_hits * (F_SPHERE_HIT - F_SPHERE_MISS);
+    st.add(RTMI_STAT_LEAF_TESTS, real_sph + real_pl);
+    st.fl += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE) + sphere_hits * (F_SPHERE_HIT - F_SPHERE_MISS);
     if (MODE == MODE_ANY) { if (bt < f2u_(t_limit)) best.leaf = 0u; } // (which leaf: nobody asks)
     else if (MODE == MODE_CLOSEST) { best.t = u2f_(bt); best.leaf = bl; }  // (best.ord of a leaf of the tables: prepare knows it)
 }
@@ -1084,8 +1141,8 @@ __device__ __forceinline__ void tri_leaf(const DWTri &w, uint32_t li, const Ray<
             }
         }
     }
-    st.c[RTMI_STAT_LEAF_TESTS]++;
-    st.flops += F_XFORM + fl;
+    st.inc(RTMI_STAT_LEAF_TESTS);
+    st.fl += F_XFORM + fl;
     if (hit && li == origin_leaf) { // the spawn point itself (see leaf_roots)
         float forced = -max_(abs_(t), 1e-30f);
         if (w.smooth) {
@@ -1150,7 +1207,7 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
         bool pop = false;
         if ((cur & ENT_KIND) == ENT_TRIS) {
             const uint32_t first = cur & ENT_TRI_FIRST_MASK, count = ((cur >> ENT_TRI_FIRST_BITS) & 15u) + 1u;
-            if (first + count > sc.n_btris) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: an entry that is not the builder's must not become an address)
+            if (first + count > sc.n_btris) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: an entry that is not the builder's must not become an address)
             if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
                 for (uint32_t i = 0; i < count; ++i) {
                     const DWTri &w = sc.btris[first + i]; // (wave-uniform index: a scalar load)
@@ -1161,24 +1218,24 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
             pop = true;
         } else if (UNITS && (cur & ENT_KIND) == ENT_LEAF) { // a primitive that is not a triangle
             const uint32_t li = cur & ~ENT_KIND;
-            if (li >= sc.n_leaves) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            if (li >= sc.n_leaves) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: see above)
             if (in && !(MODE == MODE_ANY && best.leaf != NONE))
                 plain_leaf<float, MODE>(sc, li, sc.leaves[li], sc.leaves[li].kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return;
             pop = true;
         } else if (UNITS && (cur & ENT_KIND) == 0u) { // a CSG root
-            if (cur >= sc.n_nodes) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            if (cur >= sc.n_nodes) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: see above)
             const DNode &nd = sc.nodes[cur];
             const uint32_t leaf_first = nd.leaf_first, leaf_count = nd.leaf_count;
-            if (!(nd.flags & NODE_CSGROOT) || leaf_first + leaf_count > sc.n_leaves) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never)
+            if (!(nd.flags & NODE_CSGROOT) || leaf_first + leaf_count > sc.n_leaves) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never)
             if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
-                st.c[RTMI_STAT_NODE_VISITS]++;
+                st.inc(RTMI_STAT_NODE_VISITS);
                 csg_root<float, MODE>(sc, leaf_first, leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             }
             if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return;
             pop = true;
         } else {
-            if ((cur & ENT_KIND) != ENT_BVH || (cur & ~ENT_KIND) >= sc.n_bvh2) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: see above)
+            if ((cur & ENT_KIND) != ENT_BVH || (cur & ~ENT_KIND) >= sc.n_bvh2) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: see above)
             const DBvh2 &n = sc.bvh2[cur & ~ENT_KIND];
             const float hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
             float t0 = 0, t1 = 0;
@@ -1186,9 +1243,9 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
             if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
                 h0 = slab2(n.lo0, n.hi0, ray, inv_d, lo, hi, t0);
                 h1 = slab2(n.lo1, n.hi1, ray, inv_d, lo, hi, t1);
-                st.c[RTMI_STAT_NODE_VISITS]++;
-                st.c[RTMI_STAT_AABB_TESTS] += 2;
-                st.flops += 2 * F_AABB;
+                st.inc(RTMI_STAT_NODE_VISITS);
+                st.add(RTMI_STAT_AABB_TESTS, 2);
+                st.fl += 2 * F_AABB;
             }
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
             if ((m0 | m1) == 0ull) pop = true;
@@ -1202,7 +1259,7 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
                 if (sp < PACKET_STACK) { // (the host checks the depth: always true)
                     if (lane == writer) { stk[0][sp] = far; stk[1][sp] = (uint32_t)fm; stk[2][sp] = (uint32_t)(fm >> 32); }
                     ++sp;
-                } else st.c[RTMI_STAT_OVERFLOW] = 1;
+                } else st.flag(RTMI_STAT_OVERFLOW);
                 cur = one_first ? n.child[1] : n.child[0];
                 mask = one_first ? m1 : m0;
             }
@@ -1235,14 +1292,14 @@ __device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<
     int sp = 0;
     auto push = [&](uint32_t v) {
         if (sp < PACKET_STACK) { if (lane == writer) stk[0][sp] = v; ++sp; }
-        else st.c[RTMI_STAT_OVERFLOW] = 1; // (the host checks the tree's need against PACKET_STACK: never)
+        else st.flag(RTMI_STAT_OVERFLOW); // (the host checks the tree's need against PACKET_STACK: never)
     };
     for (uint32_t c = sc.root_child_count; c-- > 0;) push(sc.root_child_first + c); // popped first to last
     while (sp > 0) {
         if (MODE == MODE_ANY && __ballot(best.leaf == NONE) == 0ull) return; // every ray of the wave is shadowed
         --sp;
         const uint32_t top = __builtin_amdgcn_readfirstlane(stk[0][sp]);
-        if (top >= sc.n_nodes) { st.c[RTMI_STAT_OVERFLOW] = 1; return; } // (never: a stack entry must not become an address unchecked)
+        if (top >= sc.n_nodes) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: a stack entry must not become an address unchecked)
         const DNode &nd = sc.nodes[top];
         const uint32_t flags = nd.flags;
         if (MODE == MODE_ANY && !(flags & NODE_CAST_SHADOW)) continue;
@@ -1251,15 +1308,15 @@ __device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<
         const float hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
         bool h = !(MODE == MODE_ANY && best.leaf != NONE);
         if ((flags & NODE_GATED) && h) {
-            st.c[RTMI_STAT_AABB_TESTS]++;
-            st.flops += F_AABB;
+            st.inc(RTMI_STAT_AABB_TESTS);
+            st.fl += F_AABB;
             h = slab(nd, ray, inv_d, lo, hi);
         }
         const unsigned long long hm = __ballot(h);
         if (hm == 0ull) continue;
-        if (h) st.c[RTMI_STAT_NODE_VISITS]++;
+        if (h) st.inc(RTMI_STAT_NODE_VISITS);
         if (flags & (NODE_TRIBVH | NODE_CSGROOT)) { // the node's own BVH, or the CSG root itself as a one-entry tree (its NODE_VISITS is counted there)
-            if (h && (flags & NODE_CSGROOT)) st.c[RTMI_STAT_NODE_VISITS]--;
+            if (h && (flags & NODE_CSGROOT)) st.add(RTMI_STAT_NODE_VISITS, 0xFFFFFFFFu);
             const uint32_t entry = (flags & NODE_TRIBVH) ? nd.csg_count : top;
             if (sc.has_units) packet_tris<MODE, true>(sc, entry, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             else packet_tris<MODE, false>(sc, entry, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
@@ -1347,7 +1404,7 @@ __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> 
     auto push = [&](uint32_t v) {
         if (sp < LDS_NODES) { lds[sp][lane] = v; ++sp; }
         else if (sp < NODE_STACK) { deep[sp - LDS_NODES] = v; ++sp; }
-        else st.c[RTMI_STAT_OVERFLOW] = 1;
+        else st.flag(RTMI_STAT_OVERFLOW);
     };
     for (;;) {
         uint32_t w_first = 0, w_count = 0, w_flags = 0, w_aux = 0;
@@ -1362,11 +1419,11 @@ __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> 
             const DNode nd = sc.nodes[top];
             if (MODE == MODE_ANY && !(nd.flags & NODE_CAST_SHADOW)) continue;
             if (nd.flags & NODE_GATED) {
-                st.c[RTMI_STAT_AABB_TESTS]++;
-                st.flops += F_AABB;
+                st.inc(RTMI_STAT_AABB_TESTS);
+                st.fl += F_AABB;
                 if (!slab(nd, ray, inv_d, lo, hi)) continue;
             }
-            st.c[RTMI_STAT_NODE_VISITS]++;
+            st.inc(RTMI_STAT_NODE_VISITS);
             if (!(nd.flags & NODE_CSGROOT)) {
                 // children are popped first to last; sorted children (two, by centre along an axis) last to first when the
                 // ray runs down that axis: the nearer one first
@@ -1621,7 +1678,7 @@ __device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &
     Hit<R> dummy = {Lim<R>::inf(), NONE, 0};
     traverse<R, MODE_COLLECT, TREE>(sc, ray, origin_leaf, origin_side, dummy, h.t, h.leaf, h.ord, open, st);
     if ((open.best != NONE && open.best >= sc.n_leaves) || (open.other != NONE && open.other >= sc.n_leaves)) { // (never: see color_at)
-        st.c[RTMI_STAT_OVERFLOW] = 1; open.best = NONE; open.other = NONE;
+        st.flag(RTMI_STAT_OVERFLOW); open.best = NONE; open.other = NONE;
     }
     c.n1 = open.best != NONE ? leaf_ior<R, TREE>(sc, open.best) : (R)1;
     if (open.hit_parity & 1u) c.n2 = open.other != NONE ? leaf_ior<R, TREE>(sc, open.other) : (R)1;
@@ -1639,7 +1696,8 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
 // entry laid out [entry][dword][lane] (conflict-free), 12 KB per wave = 12 waves per CU, which is the occupancy the
 // register budget allows anyway; deeper entries and the f64 validation mode use a per-lane array (scratch memory).
 // Recursion depth 5/6 scenes therefore push nothing to HBM.  One wave per workgroup (blockDim.x == 64) is assumed.
-constexpr int LDS_PEND = 5;      // flat scenes (a ray tree of depth 5 never holds more; with the scene block: 12.3 KB per wave)
+constexpr int LDS_PEND = 4;      // flat scenes (a fifth pending ray - five refractions waiting at once, one per level of a depth-5 tree - goes to
+                                 // scratch: rare, and the 2 KB are what the counter block and the pair tables live in; 12.3 KB per wave in all)
 constexpr int LDS_PEND_TREE = 4; // tree scenes share the 12 KB with the node stack (LDS_NODES); they do not stage the scene block
 constexpr uint32_t PEND_LEAF_BITS = 26, PEND_LEAF_MASK = (1u << PEND_LEAF_BITS) - 1u; // leaf | side << 26 | remaining << 27
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -1696,7 +1754,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<
                                             Stats &st) {
     if (in.kind == IL_OMNI) return false;
     if (in.kind == IL_NOLIGHT) return true;
-    st.c[RTMI_STAT_SHADOW]++;
+    st.inc(RTMI_STAT_SHADOW);
     if (RTMI_SKIP & 16) return false;
     Ray<R> sray = {p, in.direction};
     V3<R> to_light = in.origin - p;
@@ -1826,7 +1884,7 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
         const V3<R> power = mk<R>(div_((R)(ph.rgbf & 255u) * x, (R)255), div_((R)((ph.rgbf >> 8) & 255u) * x, (R)255), div_((R)((ph.rgbf >> 16) & 255u) * x, (R)255));
         total = total + power * w;
     }
-    st.flops += visited * F_PHOTON_VISIT + (uint32_t)cnt * F_PHOTON_GATHER + F_PHOTON_ESTIMATE;
+    st.fl += visited * F_PHOTON_VISIT + (uint32_t)cnt * F_PHOTON_GATHER + F_PHOTON_ESTIMATE;
     return had(surface_color, total) * rcp_((R)3.14159265358979323846 * square_radius); // (Color / f64 is scale(1 / x), color.rs:145-149)
 }
 
@@ -1846,14 +1904,14 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
     __shared__ uint32_t lds_pend[sizeof(R) == 4 ? LP : 1][8][64];
     bool first = true;
     for (;;) {
-        if (cls == RTMI_STAT_PRIMARY) st.c[RTMI_STAT_PRIMARY]++;
-        else if (cls == RTMI_STAT_REFLECTION) st.c[RTMI_STAT_REFLECTION]++;
-        else st.c[RTMI_STAT_REFRACTION]++;
+        if (cls == RTMI_STAT_PRIMARY) st.inc(RTMI_STAT_PRIMARY);
+        else if (cls == RTMI_STAT_REFLECTION) st.inc(RTMI_STAT_REFLECTION);
+        else st.inc(RTMI_STAT_REFRACTION);
         Hit<R> h = {Lim<R>::inf(), NONE, 0};
         Open<R> unused;
         traverse<R, MODE_CLOSEST, TREE>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
         bool spawned = false;
-        if (h.leaf != NONE && h.leaf >= sc.n_leaves) { st.c[RTMI_STAT_OVERFLOW] = 1; h.leaf = NONE; } // (never: a leaf index must not become an address unchecked)
+        if (h.leaf != NONE && h.leaf >= sc.n_leaves) { st.flag(RTMI_STAT_OVERFLOW); h.leaf = NONE; } // (never: a leaf index must not become an address unchecked)
         if (h.leaf != NONE) {
             Comps<R> c;
             uint32_t kind, material;
@@ -1863,7 +1921,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
             V3<R> over_point = c.point + c.normalv * EPS;
             // Phong::color_at (materials.rs:239-244): patterns are looked up at comps.point
             V3<R> surface_color = ld3(m.color);
-            st.flops += F_PREPARE + (((kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) ? F_SMOOTH_NORMAL : 0u) + F_COMBINE;
+            st.fl += F_PREPARE + (((kind & LEAF_KIND_MASK) == RTMI_SMOOTH_TRIANGLE) ? F_SMOOTH_NORMAL : 0u) + F_COMBINE;
             if (m.pattern >= 0 && !(RTMI_SKIP & 1)) {
                 bool done = false;
                 if constexpr (staged_v<R, TREE>) {
@@ -1871,14 +1929,14 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                     if (slot != NONE) { // world point -> pattern space in one step, from the LDS block
                         const DPattern<float> &pat = *reinterpret_cast<const DPattern<float> *>(lds_scene() + LDS_PATS_AT + slot * (uint32_t)PAT_DW);
                         surface_color = pattern_at(pat, c.point);
-                        st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u); // (priced like the reference's two steps)
+                        st.fl += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u); // (priced like the reference's two steps)
                         done = true;
                     }
                 }
                 if (!done) {
                     const DPattern<R> &pat = sc.patterns[m.pattern];
                     surface_color = pattern_at(pat, xf_point(sc.leaves[h.leaf].inv, c.point));
-                    st.flops += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u);
+                    st.fl += F_PATTERN_XF + F_PATTERN_EVAL + (pat.pad ? F_PATTERN_XF : 0u);
                 }
             }
             CYC3_END(st, 1, c_prep);
@@ -1898,7 +1956,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                 }
                 if (!staged) in = incoming_at(sc.lights[li], over_point, rng);
                 bool in_shadow = is_shadowed<R, TREE>(sc, in, over_point, h.leaf, c.side_plus ? SIDE_PLUS : 0u, st);
-                st.flops += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
+                st.fl += in.kind == IL_RAY ? (in_shadow ? F_LIGHT_SHADOWED : F_LIGHT_RAY) : (in.kind == IL_OMNI ? F_LIGHT_OMNI : 0u);
                 CYC3_BEGIN(c_light);
                 if (RTMI_SKIP & 2) surface = surface + surface_color * (in_shadow ? (R)0 : (R)0.5); else
                 surface = surface + lighting(m, surface_color, in, c.eyev, c.normalv, in_shadow);
@@ -1919,12 +1977,12 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
             R w_refl = weight * m.reflective, w_refr = weight * m.transparency;
             if (m.reflective > (R)0 && m.transparency > (R)0 && remaining > 0) { // materials.rs:406-408
                 R reflectance = schlick(c.eyev, c.normalv, c.n1, c.n2);
-                st.flops += F_SCHLICK;
+                st.fl += F_SCHLICK;
                 w_refl *= reflectance;
                 w_refr *= (R)1 - reflectance;
             }
             Ray<R> refr_ray = ray;
-            st.flops += (do_refl ? F_WEIGHT : 0u) + (do_refr ? F_WEIGHT + F_REFRACT_DIR : 0u);
+            st.fl += (do_refl ? F_WEIGHT : 0u) + (do_refr ? F_WEIGHT + F_REFRACT_DIR : 0u);
             if (do_refr) { // materials.rs:319-326
                 R n_ratio = div_(c.n1, c.n2);
                 R cos_i = dot(c.eyev, c.normalv);
@@ -1938,7 +1996,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
                 }
             }
             if (do_refl) {
-                if (do_refr && pend.full()) st.c[RTMI_STAT_OVERFLOW] = 1; // (unreachable while max_depth <= MAX_DEPTH: the ray would be lost)
+                if (do_refr && pend.full()) st.flag(RTMI_STAT_OVERFLOW); // (unreachable while max_depth <= MAX_DEPTH: the ray would be lost)
                 if (do_refr && !pend.full()) {
                     Pending<R> e;
                     e.o = refr_ray.o; e.d = refr_ray.d; e.weight = w_refr;

@@ -58,7 +58,7 @@ __device__ __forceinline__ void flush_stats(const Stats &st, unsigned long long 
 #pragma unroll
     for (int i = 0; i < RTMI_N_STATS; ++i) {
         if (i == RTMI_STAT_FLOPS || i == RTMI_STAT_FLOPS_SECOND) continue;
-        uint32_t s = wave_sum(st.c[i]);
+        uint32_t s = wave_sum(st.get(i));
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
     }
     unsigned long long f = st.flops;
@@ -99,17 +99,30 @@ template <typename R> __device__ __forceinline__ V3<R> shfl3(V3<R> v, int src) {
 }
 
 __device__ __forceinline__ void stats_zero(Stats &s) {
-#pragma unroll
-    for (int i = 0; i < RTMI_N_STATS; ++i) s.c[i] = 0;
-    s.flops = 0;
+    s.zero();
 #ifdef RTMI_CYCLES
-    s.cyc[0] = s.cyc[1] = s.cyc[2] = 0;
     s.cyc[3] = 0ull - __builtin_readcyclecounter(); // + the clock at flush_stats = the cycles between
 #endif
 }
+// The counters of a sampling loop: in the wave's LDS block for the f32 flat-scene kernels, else in registers.  (Measured, A/B
+// on whole frames: flat scenes +7 ... +8.5 % with the block - chapter-11a 79.8 -> 86.4 Grays/s, the spills gone; tree scenes
+// -13 ... -20 % - a tree walk counts a node visit, box tests and leaf tests per step, and that many LDS atomics cost
+// more than the registers they free.  The photon-map kernels' LDS is full of candidate heaps.)
+template <typename R, bool TREE, bool PHOTON> __device__ __forceinline__ void stats_begin(Stats &s, int lane) {
+#ifndef RTMI_TREE_STATS_LDS
+#define RTMI_TREE_STATS_LDS 0
+#endif
+    if constexpr (sizeof(R) == 4 && !PHOTON && (!TREE || RTMI_TREE_STATS_LDS)) s.zero_in_lds(stats_block<TREE>(), TREE ? STAT_SLOTS_TREE : STAT_SLOTS_FLAT, lane);
+    else s.zero();
+#ifdef RTMI_CYCLES
+    s.cyc[3] = 0ull - __builtin_readcyclecounter();
+#endif
+}
+// b's counters (a sample's, possibly in LDS) added to a's (registers)
 __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 #pragma unroll
-    for (int i = 0; i < RTMI_N_STATS; ++i) a.c[i] += b.c[i];
+    for (int i = 0; i < RTMI_N_STATS; ++i)
+        if (i != RTMI_STAT_FLOPS && i != RTMI_STAT_FLOPS_SECOND) a.c[i] += b.get(i);
     a.flops += b.flops;
 #ifdef RTMI_CYCLES
     a.cyc[0] += b.cyc[0]; a.cyc[1] += b.cyc[1]; a.cyc[2] += b.cyc[2];
@@ -120,12 +133,14 @@ __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 template <typename R, bool TREE, bool PHOTON = false>
 __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<double> &cam, Rng &rng, Stats &st, int px, int py, uint32_t s) {
     rng_begin(rng, (uint32_t)(py * cam.hsize + px), s);
-    st.c[RTMI_STAT_SAMPLES]++;
-    st.flops += camera_flops(cam);
+    st.inc(RTMI_STAT_SAMPLES);
+    st.fl += camera_flops(cam);
     CYC3_BEGIN(c_cam);
     Ray<R> ray = camera_ray<R>(cam, px, py, s != 0, rng);
     CYC3_END(st, 0, c_cam);
-    return color_at<R, TREE, PHOTON>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
+    const V3<R> c = color_at<R, TREE, PHOTON>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
+    stats_sample_end(st);
+    return c;
 }
 
 // Further samples the stopping rule is expected to ask of a pixel with these running sums.  The reference's sum of squares
@@ -233,11 +248,11 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
     // (the work pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
     // written in this kernel and fetch the wave-uniform ones with scalar loads)
     stage_scene<R, TREE>(sc);
+    const int lane = threadIdx.x & 63;
     Stats st;
-    stats_zero(st);
+    stats_begin<R, TREE, PHOTON>(st, lane);
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
-    const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int sub = rp.tile_rows >> 3; // 8-row rows per ownership tile
     // A wave visit takes the first rp.first samples of rp.ppw pixels, in one of two ways that add the samples up in the
@@ -483,19 +498,19 @@ __device__ __forceinline__ void sum_up_units(const DCamera<double> &cam, float *
         const unsigned long long sb = __ballot(!need_more(cam, sj, qj, (R)cntj, cntj));
         const int k = sb ? __ffsll((long long)sb) : 64;
         if (lane < k) {
-            st.c[RTMI_STAT_PRIMARY] += w[0] & 0xFFu; st.c[RTMI_STAT_SAMPLES] += (w[0] >> 8) & 0xFFu; st.c[RTMI_STAT_OVERFLOW] += w[0] >> 16;
-            st.c[RTMI_STAT_REFLECTION] += w[1]; st.c[RTMI_STAT_REFRACTION] += w[2];
-            st.c[RTMI_STAT_SHADOW] += w[3]; st.c[RTMI_STAT_LEAF_TESTS] += w[4];
-            st.c[RTMI_STAT_NODE_VISITS] += w[5]; st.c[RTMI_STAT_AABB_TESTS] += w[6];
+            st.add(RTMI_STAT_PRIMARY, w[0] & 0xFFu); st.add(RTMI_STAT_SAMPLES, (w[0] >> 8) & 0xFFu); st.add(RTMI_STAT_OVERFLOW, w[0] >> 16);
+            st.add(RTMI_STAT_REFLECTION, w[1]); st.add(RTMI_STAT_REFRACTION, w[2]);
+            st.add(RTMI_STAT_SHADOW, w[3]); st.add(RTMI_STAT_LEAF_TESTS, w[4]);
+            st.add(RTMI_STAT_NODE_VISITS, w[5]); st.add(RTMI_STAT_AABB_TESTS, w[6]);
             st.flops += w[7];
-        } else st.c[RTMI_STAT_DISCARDED] += (w[0] >> 8) & 0xFFu;
+        } else st.add(RTMI_STAT_DISCARDED, (w[0] >> 8) & 0xFFu);
         sum = shfl3(sj, k - 1); sos = shfl3(qj, k - 1);
         cnt += (uint32_t)k;
         stopped = sb != 0;
     }
-    if (c < n) st.c[RTMI_STAT_DISCARDED] += (nst[0] >> 8) & 0xFFu; // (already fetched)
+    if (c < n) st.add(RTMI_STAT_DISCARDED, (nst[0] >> 8) & 0xFFu); // (already fetched)
 #pragma unroll 1
-    for (++c; c < n; ++c) st.c[RTMI_STAT_DISCARDED] += (chunks[base + c].st[0][lane] >> 8) & 0xFFu;
+    for (++c; c < n; ++c) st.add(RTMI_STAT_DISCARDED, (chunks[base + c].st[0][lane] >> 8) & 0xFFu);
     if (lane != 0) return;
     if (stopped) {
         const R inv = (R)1 / (R)cnt;
@@ -655,7 +670,7 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
             const uint32_t s = cnt0 + (uint32_t)j;
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
-            stats_zero(ls);
+            stats_begin<R, TREE, PHOTON>(ls, lane);
             if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, ox, oy, s);
             // the pixel's sums after each of the group's samples, added up one after the other like the reference's loop
             V3<R> sj, qj;
@@ -666,7 +681,7 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
             const unsigned long long gb = wide ? sb : (sb >> (r * G)) & ((1ull << G) - 1ull);
             const int k_used = gb ? __ffsll((long long)gb) : G; // samples of this group that the reference would have taken
             if (has && j < k_used) stats_add(st, ls);
-            else st.c[RTMI_STAT_DISCARDED] += ls.c[RTMI_STAT_SAMPLES];
+            else st.add(RTMI_STAT_DISCARDED, ls.get(RTMI_STAT_SAMPLES));
             // hand the result back to the pixel's own lane
             const bool upd = act && (!wide || lane == owner);
             const int gbase = upd ? (wide ? 0 : lane * G) : lane;
@@ -722,14 +737,14 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
             const uint32_t s = __shfl(bc, (int)i, 64) + (uint32_t)lane;
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
-            stats_zero(ls);
+            stats_begin<R, TREE, PHOTON>(ls, lane);
             if (!(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, px, py, s);
             DChunk<R> *ch = wk_chunks + (u0 + i);
             ch->col[0][lane] = c.x; ch->col[1][lane] = c.y; ch->col[2][lane] = c.z;
-            ch->st[0][lane] = (ls.c[RTMI_STAT_PRIMARY] & 0xFFu) | ((ls.c[RTMI_STAT_SAMPLES] & 0xFFu) << 8) | (min(ls.c[RTMI_STAT_OVERFLOW], 0xFFFFu) << 16);
-            ch->st[1][lane] = ls.c[RTMI_STAT_REFLECTION]; ch->st[2][lane] = ls.c[RTMI_STAT_REFRACTION];
-            ch->st[3][lane] = ls.c[RTMI_STAT_SHADOW]; ch->st[4][lane] = ls.c[RTMI_STAT_LEAF_TESTS];
-            ch->st[5][lane] = ls.c[RTMI_STAT_NODE_VISITS]; ch->st[6][lane] = ls.c[RTMI_STAT_AABB_TESTS];
+            ch->st[0][lane] = (ls.get(RTMI_STAT_PRIMARY) & 0xFFu) | ((ls.get(RTMI_STAT_SAMPLES) & 0xFFu) << 8) | (min(ls.get(RTMI_STAT_OVERFLOW), 0xFFFFu) << 16);
+            ch->st[1][lane] = ls.get(RTMI_STAT_REFLECTION); ch->st[2][lane] = ls.get(RTMI_STAT_REFRACTION);
+            ch->st[3][lane] = ls.get(RTMI_STAT_SHADOW); ch->st[4][lane] = ls.get(RTMI_STAT_LEAF_TESTS);
+            ch->st[5][lane] = ls.get(RTMI_STAT_NODE_VISITS); ch->st[6][lane] = ls.get(RTMI_STAT_AABB_TESTS);
             ch->st[7][lane] = (uint32_t)ls.flops;
         }
     }
@@ -747,12 +762,7 @@ __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_l
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Stats st;
-#pragma unroll
-    for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
-    st.flops = 0;
-#ifdef RTMI_CYCLES
-    st.cyc[0] = st.cyc[1] = st.cyc[2] = st.cyc[3] = 0;
-#endif
+    st.zero();
     Rng rng;
     rng.k0 = seed_lo; rng.k1 = seed_hi;
     rng_begin(rng, (uint32_t)i, 0);
@@ -794,12 +804,7 @@ template <typename R, bool STORE>
 __global__ void __launch_bounds__(64) photon_trace_kernel(DScene<R> sc, DPhotonTrace pt, rtmi_photon *out, uint32_t *counts, const uint32_t *offsets,
                                                           unsigned long long *counters) {
     Stats st;
-#pragma unroll
-    for (int k = 0; k < RTMI_N_STATS; ++k) st.c[k] = 0;
-    st.flops = 0;
-#ifdef RTMI_CYCLES
-    st.cyc[0] = st.cyc[1] = st.cyc[2] = st.cyc[3] = 0;
-#endif
+    st.zero();
     trace_photons<R, STORE>(sc, pt, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, out, counts, offsets, counters, st);
 }
 
