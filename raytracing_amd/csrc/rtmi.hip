@@ -337,7 +337,7 @@ struct rtmi_scene {
     uint32_t *quick = nullptr; // LDS records of the first top-level leaves (rtmi_device.hpp stage_scene)
     uint32_t n_quick = 0;
     uint32_t *pairs = nullptr, *others = nullptr; // the pair tables of the LDS block; the top-level leaves that are not in them
-    uint32_t n_others = 0, pair_counts = 0, real_counts = 0;
+    uint32_t n_others = 0, pair_counts = 0, real_counts = 0, xpair_counts = 0;
     DScene<float> h32;
     DScene<double> h64;
     int num_cu = 256;
@@ -1084,7 +1084,7 @@ static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) 
 // what the flat f32 kernels stage in LDS (rtmi_device.hpp stage_scene) and the list that goes with it
 struct QuickTables {
     std::vector<uint32_t> quick, pairs, others;
-    uint32_t pair_counts = 0, real_counts = 0;
+    uint32_t pair_counts = 0, real_counts = 0, xpair_counts = 0;
 };
 
 template <typename R>
@@ -1219,12 +1219,39 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
         // component by component; a group of an odd number of leaves ends with a filler no ray hits.  Every other
         // top-level leaf goes on the `others` list.
         std::vector<uint32_t> group[4]; // spheres casting / not, planes casting / not
+        std::vector<uint32_t> xgroup[2]; // spheres under a general affine transform (LEAF_XPAIR): casting / not
         for (size_t i = 0; i < L.nodes[0].leaf_count; ++i) {
-            const uint32_t kind = i < nq ? (*quick)[i * QUICK_DW] : 0u;
+            uint32_t kind = i < nq ? (*quick)[i * QUICK_DW] : 0u;
+            if (i < nq && !(kind & LEAF_QUICK) && (kind & LEAF_KIND_MASK) == RTMI_SPHERE) {
+                const double *li = d->leaves[L.leaf_orig[i]].inv;
+                const bool affine = li[12] == 0 && li[13] == 0 && li[14] == 0 && li[15] == 1;
+                std::vector<uint32_t> &xg = xgroup[(kind & LEAF_CAST_SHADOW) ? 0 : 1];
+                // (room: LDS_XPAIRS records for both groups, each rounded up to whole pairs)
+                const size_t pairs_if = (xgroup[0].size() + (&xg == &xgroup[0] ? 1 : 0) + 1) / 2 + (xgroup[1].size() + (&xg == &xgroup[1] ? 1 : 0) + 1) / 2;
+                if (affine && pairs_if <= (size_t)LDS_XPAIRS) { xg.push_back((uint32_t)i); (*quick)[i * QUICK_DW] = kind | LEAF_XPAIR; continue; }
+            }
             if (!(kind & LEAF_QUICK)) { qt->others.push_back((uint32_t)i); continue; }
             group[((kind & LEAF_FAST) ? 0 : 2) + ((kind & LEAF_CAST_SHADOW) ? 0 : 1)].push_back((uint32_t)i);
         }
-        qt->pairs.assign((size_t)LDS_PAIRS * PAIR_DW, 0u);
+        qt->pairs.assign((size_t)PAIRS_IMAGE_DW, 0u);
+        {   // the transformed-sphere table: m0a m0b ... m11a m11b id0 id1 - -; a filler is the unit sphere 1e15 away
+            uint32_t n_x = 0, xp[2] = {0, 0};
+            for (int gi = 0; gi < 2; ++gi)
+                for (size_t k = 0; k < xgroup[gi].size(); k += 2, ++n_x, ++xp[gi]) {
+                    uint32_t *rec = qt->pairs.data() + (size_t)LDS_PAIRS * PAIR_DW + (size_t)n_x * XPAIR_DW;
+                    for (int h = 0; h < 2; ++h) {
+                        float m[12] = {1, 0, 0, 1e15f, 0, 1, 0, 0, 0, 0, 1, 0};
+                        uint32_t id = 0xFFFFFFFEu;
+                        if (k + h < xgroup[gi].size()) {
+                            id = xgroup[gi][k + h];
+                            for (int a = 0; a < 12; ++a) m[a] = (float)leaves[id].inv[a];
+                        }
+                        for (int a = 0; a < 12; ++a) memcpy(rec + 2 * a + h, &m[a], 4);
+                        rec[24 + h] = id;
+                    }
+                }
+            qt->xpair_counts = (xp[0] + xp[1]) | (xp[0] << 8) | ((uint32_t)(xgroup[0].size() + xgroup[1].size()) << 16) | ((uint32_t)xgroup[0].size() << 24);
+        }
         uint32_t n_pairs = 0, pc[4] = {0, 0, 0, 0};
         for (int gi = 0; gi < 4; ++gi) {
             for (size_t k = 0; k < group[gi].size(); k += 2, ++n_pairs, ++pc[gi]) {
@@ -1306,10 +1333,10 @@ template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_d
     for (const DNode &n : L.nodes) if (n.flags & NODE_CSGROOT) h.has_units = 1;
     if (sizeof(R) == 4 && s->bvh_has_units) h.has_units = 1;
     h.quick = nullptr; h.n_quick = 0; h.n_lds_materials = 0; h.n_lds_lights = 0;
-    h.pairs = nullptr; h.others = nullptr; h.n_others = 0; h.pair_counts = 0; h.real_counts = 0;
+    h.pairs = nullptr; h.others = nullptr; h.n_others = 0; h.pair_counts = 0; h.real_counts = 0; h.xpair_counts = 0; h.pad5 = 0;
     if (sizeof(R) == 4) {
         h.quick = s->quick; h.n_quick = s->n_quick;
-        h.pairs = s->pairs; h.others = s->others; h.n_others = s->n_others; h.pair_counts = s->pair_counts; h.real_counts = s->real_counts;
+        h.pairs = s->pairs; h.others = s->others; h.n_others = s->n_others; h.pair_counts = s->pair_counts; h.real_counts = s->real_counts; h.xpair_counts = s->xpair_counts;
         h.n_lds_materials = d->n_materials <= LDS_MATS ? (uint32_t)d->n_materials : 0u;
         h.n_lds_lights = d->n_lights <= LDS_LIGHTS ? (uint32_t)d->n_lights : 0u;
     }
@@ -1440,7 +1467,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &qt);
     if (rc == RTMI_OK) { s->n_quick = (uint32_t)std::min<size_t>(L.nodes[0].leaf_count, (size_t)LDS_QUICK); rc = upload(&s->quick, qt.quick); }
     if (rc == RTMI_OK) rc = upload(&s->pairs, qt.pairs);
-    if (rc == RTMI_OK) { s->n_others = (uint32_t)qt.others.size(); s->pair_counts = qt.pair_counts; s->real_counts = qt.real_counts; rc = upload(&s->others, qt.others); }
+    if (rc == RTMI_OK) { s->n_others = (uint32_t)qt.others.size(); s->pair_counts = qt.pair_counts; s->real_counts = qt.real_counts; s->xpair_counts = qt.xpair_counts; rc = upload(&s->others, qt.others); }
     if (rc == RTMI_OK) rc = upload_typed<double>(desc, L, s->f64);
     if (rc == RTMI_OK && (rc = pool_acquire(dev)) == RTMI_OK) s->pooled = true;
     void *unused_scratch = nullptr;

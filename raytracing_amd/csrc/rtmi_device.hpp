@@ -49,6 +49,7 @@ constexpr uint32_t LEAF_CAST_SHADOW = 1u << 9;
 constexpr uint32_t LEAF_FAST = 1u << 10; // f32 only: sphere under a similarity transform, tested in world space (fast[])
 constexpr uint32_t LEAF_QUICK = 1u << 12; // f32 only, top-level leaves: the leaf's LDS record holds all that its intersection test and its normal need
                                           // (a LEAF_FAST sphere: centre and squared radius; a plane: row 1 of the world->object matrix)
+constexpr uint32_t LEAF_XPAIR = 1u << 13; // f32 only, top-level leaves: a sphere under a general affine transform that the transformed-sphere pair table holds
 constexpr uint32_t LEAF_BOUND = 1u << 11; // f32 only: fast[] = a world-space sphere (centre, radius^2, slightly inflated) that
                                           // contains the leaf; a ray whose line misses it has no roots (leaves below nodes only)
 
@@ -202,6 +203,8 @@ template <typename R> struct DScene {
     const uint32_t *others;    // n_others device leaf indices, ascending
     uint32_t pair_counts;      // pairs of the tables, a byte each: spheres | shadow-casting spheres << 8 | planes << 16 | shadow-casting planes << 24
     uint32_t real_counts;      // the leaves in them (a table of an odd number of leaves ends with a filler), same bytes
+    uint32_t xpair_counts;     // the table of spheres under a general affine transform: pairs | shadow-casting pairs << 8 | leaves << 16 | shadow-casting leaves << 24
+    uint32_t pad5;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -222,7 +225,12 @@ template <typename R> struct DScene {
 // The flat-scene kernels (World::objects all primitives) use it.  The tree-scene kernels do not: their time goes into
 // node traversal, the top level is a leaf or two, and the second code path cost them registers they do not have (the
 // compiler gave resample_kernel<float, true> 248 VGPRs = 2 waves per SIMD with it).
-template <typename R, bool TREE> constexpr bool staged_v = sizeof(R) == 4 && !TREE;
+// The kind of world a kernel is compiled for (the template parameter TREE of everything below; `true` / `false` convert to
+// the first two): KIND_FLAT World::objects are all primitives, KIND_TREE anything (Groups, CSG, meshes), KIND_FLATX a flat
+// world that also has spheres under a general affine transform in the transformed-sphere table (a kernel of its own: the
+// table's loop holds 24 more registers, which cost the other flat scenes 8 % when it was compiled into their kernel).
+enum { KIND_FLAT = 0, KIND_TREE = 1, KIND_FLATX = 2 };
+template <typename R, int TREE> constexpr bool staged_v = sizeof(R) == 4 && TREE != KIND_TREE;
 constexpr int LDS_QUICK = 16, LDS_PATS = 4, LDS_MATS = 16, LDS_LIGHTS = 4;
 constexpr int QUICK_DW = 8;
 constexpr int MAT_DW = (int)(sizeof(DMaterial<float>) / 4), LIGHT_DW = (int)(sizeof(DLight<float>) / 4), PAT_DW = (int)(sizeof(DPattern<float>) / 4);
@@ -234,16 +242,28 @@ constexpr int LDS_LIGHTS_AT = LDS_MATS_AT + LDS_MATS * MAT_DW;
 //                   component by component, so that one packed instruction (v_pk_fma_f32 ...) works on both leaves.
 //                   Order: spheres that cast shadows, other spheres, planes that cast shadows, other planes; a group of
 //                   an odd number of leaves ends with a filler that no ray hits (radius^2 < 0 / a zero row).
+//   transformed     spheres under a general affine transform (the squashed spheres chapter-07 builds its walls from) the same
+//   spheres         way with their whole world->object matrix: m0a m0b m1a m1b ... m11a m11b leaf0 leaf1 - -; shadow casters
+//                   first; a filler is the unit sphere 1e15 away.  (LEAF_XPAIR in the leaf's quick record.)
 constexpr int LDS_PAIRS = 10, PAIR_DW = 12; // (16 leaves in four groups: at most 10 records)
+//                   The table has an LDS array of its own (lds_xpairs), which only the KIND_FLATX kernels allocate: LDS is
+//                   granted in 512-byte granules and 12 waves per CU leave 13,312 bytes each - the flat kernels' 12,560 fit,
+//                   with 6 records of this table on top (13,232) they still do, with 8 they did not (11 waves, -7 %).
+constexpr int LDS_XPAIRS = 6, XPAIR_DW = 28;
 constexpr int LDS_PAIRS_AT = LDS_LIGHTS_AT + LDS_LIGHTS * LIGHT_DW;
 constexpr int LDS_SCENE_DW = LDS_PAIRS_AT + LDS_PAIRS * PAIR_DW; // 644 dwords = 2.6 KB per wave
+constexpr int PAIRS_IMAGE_DW = LDS_PAIRS * PAIR_DW + LDS_XPAIRS * XPAIR_DW; // what DScene::pairs points at
 static_assert(sizeof(DMaterial<float>) % 4 == 0 && sizeof(DLight<float>) % 4 == 0 && sizeof(DPattern<float>) % 4 == 0 && LDS_PATS_AT % 4 == 0 && LDS_MATS_AT % 4 == 0 && LDS_PAIRS_AT % 4 == 0, "LDS scene block layout");
 __device__ __forceinline__ uint32_t *lds_scene() {
     __shared__ __align__(16) uint32_t s_scene[LDS_SCENE_DW];
     return s_scene;
 }
+__device__ __forceinline__ uint32_t *lds_xpairs() {
+    __shared__ __align__(16) uint32_t s_xpairs[LDS_XPAIRS * XPAIR_DW];
+    return s_xpairs;
+}
 // Called once by every kernel that traces rays, before anything else, by all lanes of the wave.
-template <typename R, bool TREE> __device__ __forceinline__ void stage_scene(const DScene<R> &sc) {
+template <typename R, int TREE> __device__ __forceinline__ void stage_scene(const DScene<R> &sc) {
     if constexpr (staged_v<R, TREE>) {
         uint32_t *s = lds_scene();
 #ifdef RTMI_HOST_EMUL // (lanes run one after the other there: each fills the whole block)
@@ -257,6 +277,10 @@ template <typename R, bool TREE> __device__ __forceinline__ void stage_scene(con
         for (uint32_t i = first; i < nm; i += step) s[LDS_MATS_AT + i] = m[i];
         for (uint32_t i = first; i < nl; i += step) s[LDS_LIGHTS_AT + i] = l[i];
         for (uint32_t i = first; i < (uint32_t)(LDS_PAIRS * PAIR_DW); i += step) s[LDS_PAIRS_AT + i] = sc.pairs[i];
+        if constexpr (TREE == KIND_FLATX) {
+            uint32_t *x = lds_xpairs();
+            for (uint32_t i = first; i < (uint32_t)(LDS_XPAIRS * XPAIR_DW); i += step) x[i] = sc.pairs[LDS_PAIRS * PAIR_DW + i];
+        }
 #ifndef RTMI_HOST_EMUL
         __syncthreads(); // (one wave per workgroup: its own writes, visible to all its lanes from here on)
 #endif
@@ -446,8 +470,8 @@ struct Stats {
             if (k < n) lds[k * 64] = 0u;
     }
 };
-template <bool TREE> __device__ __forceinline__ uint32_t *stats_block() { // (one wave per workgroup)
-    __shared__ uint32_t s_stats[TREE ? STAT_SLOTS_TREE : STAT_SLOTS_FLAT][64];
+template <int TREE> __device__ __forceinline__ uint32_t *stats_block() { // (one wave per workgroup)
+    __shared__ uint32_t s_stats[TREE == KIND_TREE ? STAT_SLOTS_TREE : STAT_SLOTS_FLAT][64];
     return &s_stats[0][0];
 }
 __device__ __forceinline__ void stats_sample_end(Stats &st) { st.flops += st.fl; st.fl = 0; }
@@ -980,6 +1004,45 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
     apply_roots<R, MODE>(li, n, t, best, t_limit, hit_leaf, hit_ord, open);
 }
 
+// Spheres under a general affine transform (LEAF_XPAIR), two per step from the transformed-sphere table: both rays into
+// object space (ray.rs:30-35: 18 packed multiply-adds for the pair), then sphere.rs:47-63 with the roots as closest
+// approach -+ half chord.  `take(id, t0, t1, true)` gets the ascending roots of every leaf that has any; `hits` counts them,
+// `tested` the leaves (fillers excluded) - see quick_pairs.
+template <int MODE, typename TAKE>
+__device__ __forceinline__ void xsphere_pairs(const DScene<float> &sc, const Ray<float> &ray, f2 ox, f2 oy, f2 oz, f2 dx, f2 dy, f2 dz, uint32_t origin_leaf,
+                                              TAKE &take, uint32_t &hits, uint32_t &tested) {
+    const uint32_t xc = sc.xpair_counts;
+    const uint32_t n = MODE == MODE_ANY ? (xc >> 8) & 255u : xc & 255u;
+    if (n == 0u) return;
+    tested += MODE == MODE_ANY ? xc >> 24 : (xc >> 16) & 255u;
+    const uint32_t *tab = lds_xpairs();
+    for (uint32_t p = 0; p < n; ++p) {
+        const uint32_t *r = tab + p * (uint32_t)XPAIR_DW;
+        f2 m[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m[k] = mk2(u2f_(r[2 * k]), u2f_(r[2 * k + 1]));
+        const uint32_t id0 = r[24], id1 = r[25];
+        const f2 px = m[0] * ox + m[1] * oy + m[2] * oz + m[3], py = m[4] * ox + m[5] * oy + m[6] * oz + m[7], pz = m[8] * ox + m[9] * oy + m[10] * oz + m[11];
+        const f2 vx = m[0] * dx + m[1] * dy + m[2] * dz, vy = m[4] * dx + m[5] * dy + m[6] * dz, vz = m[8] * dx + m[9] * dy + m[10] * dz;
+        const f2 a = vx * vx + vy * vy + vz * vz;
+        const f2 ia = mk2(rcp_(a.x), rcp_(a.y));
+        const f2 k = (vx * px + vy * py + vz * pz) * ia;
+        const f2 lx = px - vx * k, ly = py - vy * k, lz = pz - vz * k;
+        const f2 one = splat2(1.0f);
+        const f2 x = (one - (lx * lx + ly * ly + lz * lz)) * ia;
+        const bool h0 = !(x.x < 0.0f), h1 = !(x.y < 0.0f);
+        if (h0 || h1) {
+            const float s0 = sqrt_(x.x), s1 = sqrt_(x.y);
+            float t00 = -k.x - s0, t01 = s0 - k.x, t10 = -k.y - s1, t11 = s1 - k.y;
+            hits += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
+            if (origin_leaf == id0 && h0) { if (abs_(t01) < abs_(t00)) t01 = -max_(abs_(t01), 1e-30f); else t00 = -max_(abs_(t00), 1e-30f); }
+            if (origin_leaf == id1 && h1) { if (abs_(t11) < abs_(t10)) t11 = -max_(abs_(t11), 1e-30f); else t10 = -max_(abs_(t10), 1e-30f); }
+            if (MODE != MODE_COLLECT || h0) take(id0, t00, t01, true);
+            if (MODE != MODE_COLLECT || h1) take(id1, t10, t11, true);
+        }
+    }
+}
+
 // The LEAF_QUICK top-level leaves - spheres under a similarity transform as world-space spheres |p - c|^2 = r^2, planes as
 // row 1 of their world->object matrix (see leaf_roots: the ray parameter is the same in both spaces) - from the pair
 // tables of the LDS block, TWO leaves per step.  What the loops are built around:
@@ -997,7 +1060,7 @@ __device__ __forceinline__ void plain_leaf(const DScene<R> &sc, uint32_t li, con
 // Counters: every leaf of the tables is tested by every ray that comes here (as World::intersect tests every object,
 // world.rs:145-170: the reference has no early exit either), so tests and their FLOPs are wave-uniform sums plus the
 // per-lane count of sphere hits (F_SPHERE_HIT - F_SPHERE_MISS each).
-template <int MODE>
+template <int MODE, bool XP>
 __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<float> &ray, uint32_t origin_leaf, Hit<float> &best, float t_limit,
                                             uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
     const uint32_t *tab = lds_scene() + LDS_PAIRS_AT;
@@ -1005,7 +1068,7 @@ __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<f
     const uint32_t sph_all = pc & 255u, n_sph = MODE == MODE_ANY ? (pc >> 8) & 255u : sph_all;
     const uint32_t n_pl = MODE == MODE_ANY ? pc >> 24 : (pc >> 16) & 255u;
     const uint32_t real_sph = MODE == MODE_ANY ? (rc >> 8) & 255u : rc & 255u, real_pl = MODE == MODE_ANY ? rc >> 24 : (rc >> 16) & 255u;
-    if (n_sph + n_pl == 0u) return;
+    if (n_sph + n_pl + (XP ? sc.xpair_counts & 255u : 0u) == 0u) return;
     const float inv_a = rcp_(dot(ray.d, ray.d));
     const f2 ox = splat2(ray.o.x), oy = splat2(ray.o.y), oz = splat2(ray.o.z), dx = splat2(ray.d.x), dy = splat2(ray.d.y), dz = splat2(ray.d.z), ia = splat2(inv_a);
     uint32_t bt = f2u_(MODE == MODE_ANY ? Lim<float>::inf() : best.t), bl = best.leaf, sphere_hits = 0;
@@ -1068,8 +1131,14 @@ __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<f
                           apply_roots<float, MODE_COLLECT>(id1, 1, t, best, t_limit, hit_leaf, hit_ord, open); }
             }
         }
-        st.add(RTMI_STAT_LEAF_TESTS, real_sph + real_pl);
-        st.fl += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE); // (priced as the reference's tests of these leaves; hits are not told apart here)
+        uint32_t xs = real_sph, xhits = 0;
+        auto take_collect = [&](uint32_t id, float t0, float t1, bool) {
+            const float t[4] = {t0, t1, 0.0f, 0.0f};
+            apply_roots<float, MODE_COLLECT>(id, 2, t, best, t_limit, hit_leaf, hit_ord, open);
+        };
+        if constexpr (XP) xsphere_pairs<MODE_COLLECT>(sc, ray, ox, oy, oz, dx, dy, dz, origin_leaf, take_collect, xhits, xs);
+        st.add(RTMI_STAT_LEAF_TESTS, xs + real_pl);
+        st.fl += xs * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE) + xhits * (F_SPHERE_HIT - F_SPHERE_MISS); // (priced as the reference's tests of these leaves; the quick spheres' hits are not told apart here)
         return;
     }
     for (uint32_t p = 0; p < n_sph; ++p) { // sphere.rs:47-63 in world space, roots as closest approach -+ half chord
@@ -1108,8 +1177,10 @@ __device__ __forceinline__ void quick_pairs(const DScene<float> &sc, const Ray<f
         if (MODE != MODE_COLLECT || h0) take(id0, t0, 0.0f, false);
         if (MODE != MODE_COLLECT || h1) take(id1, t1, 0.0f, false);
     }
-    st.add(RTMI_STAT_LEAF_TESTS, real_sph + real_pl);
-    st.fl += real_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE) + sphere_hits * (F_SPHERE_HIT - F_SPHERE_MISS);
+    uint32_t tested_sph = real_sph;
+    if constexpr (XP) xsphere_pairs<MODE>(sc, ray, ox, oy, oz, dx, dy, dz, origin_leaf, take, sphere_hits, tested_sph);
+    st.add(RTMI_STAT_LEAF_TESTS, tested_sph + real_pl);
+    st.fl += tested_sph * (F_XFORM + F_SPHERE_MISS) + real_pl * (F_XFORM + F_PLANE) + sphere_hits * (F_SPHERE_HIT - F_SPHERE_MISS);
     if (MODE == MODE_ANY) { if (bt < f2u_(t_limit)) best.leaf = 0u; } // (which leaf: nobody asks)
     else if (MODE == MODE_CLOSEST) { best.t = u2f_(bt); best.leaf = bl; }  // (best.ord of a leaf of the tables: prepare knows it)
 }
@@ -1354,7 +1425,7 @@ __device__ __forceinline__ uint32_t (*lds_node_stack())[64] {
 //   MODE_CLOSEST: best = min t >= 0.            t_limit = +inf
 //   MODE_ANY    : best.leaf != NONE iff some shadow-casting root lies in [0, t_limit)
 //   MODE_COLLECT: open = which leaves the ray is inside of just in front of (t_limit, hit_leaf, hit_ord)
-template <typename R, int MODE, bool TREE>
+template <typename R, int MODE, int TREE>
 __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     // Top-level primitives: wave-uniform loop bounds.  Flat f32 scenes: the LEAF_QUICK ones among the first n_quick from
@@ -1362,7 +1433,7 @@ __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> 
     // tables do not hold, leaves past the block - from their record in global memory through scalar loads, with the kind
     // from the leaf's LDS record where it has one (one round trip instead of two).  f64 and tree scenes: scalar loads.
     if constexpr (staged_v<R, TREE>) {
-        quick_pairs<MODE>(sc, ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
+        quick_pairs<MODE, TREE == KIND_FLATX>(sc, ray, origin_leaf, best, t_limit, hit_leaf, hit_ord, open, st);
         if (MODE == MODE_ANY && best.leaf != NONE) return;
         const uint32_t nq = sc.n_quick;
         for (uint32_t i = 0; i < sc.n_others; ++i) {
@@ -1377,7 +1448,7 @@ __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> 
             if (MODE == MODE_ANY && best.leaf != NONE) return;
         }
     }
-    if (!TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
+    if (TREE != KIND_TREE) return; // flat scenes (World::objects are all primitives) compile without the tree / CSG machinery
     if (sc.root_child_count == 0) return;
     if constexpr (sizeof(R) == 4) { // the product path: the wave walks the tree together
         CYC_BEGIN(c_walk);
@@ -1585,7 +1656,7 @@ template <typename R> struct Comps {
 };
 
 // (kind | flags and material of the hit leaf come back too: from the leaf's LDS record if it has one)
-template <typename R, bool TREE>
+template <typename R, int TREE>
 __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, Hit<R> &h, Comps<R> &c, uint32_t &kind, uint32_t &material) {
     c.point = ray.o + ray.d * h.t; // Ray::position, ray.rs:26-28
     c.eyev = -ray.d;
@@ -1630,10 +1701,13 @@ __device__ __forceinline__ void prepare(const DScene<R> &sc, const Ray<R> &ray, 
     c.inside = dot(n, c.eyev) < (R)0;
     c.normalv = c.inside ? -n : n;
     c.side_plus = dot(xf_vector(g.inv, c.normalv), ng) > (R)0;
+    if constexpr (staged_v<R, TREE>) { // a sphere of the transformed-sphere table: its second root is where the ray leaves it (see the quick leaves above)
+        if (h.leaf < sc.n_quick && (lds_scene()[h.leaf * (uint32_t)QUICK_DW] & LEAF_XPAIR)) h.ord = c.inside ? 1u : 0u;
+    }
 }
 
 // a material / the refractive index of a leaf's material: from the LDS block where it holds them
-template <typename R, bool TREE> __device__ __forceinline__ DMaterial<R> load_material(const DScene<R> &sc, uint32_t id) {
+template <typename R, int TREE> __device__ __forceinline__ DMaterial<R> load_material(const DScene<R> &sc, uint32_t id) {
     if constexpr (staged_v<R, TREE>) {
         // (n_lds_materials is all of them or none: a wave-uniform choice between an LDS read and a global load - a per-lane
         // choice would make every access a flat load through both paths)
@@ -1641,7 +1715,7 @@ template <typename R, bool TREE> __device__ __forceinline__ DMaterial<R> load_ma
     }
     return sc.materials[id];
 }
-template <typename R, bool TREE> __device__ __forceinline__ R leaf_ior(const DScene<R> &sc, uint32_t leaf) {
+template <typename R, int TREE> __device__ __forceinline__ R leaf_ior(const DScene<R> &sc, uint32_t leaf) {
     uint32_t id = 0;
     bool have = false;
     if constexpr (staged_v<R, TREE>) {
@@ -1655,7 +1729,7 @@ template <typename R, bool TREE> __device__ __forceinline__ R leaf_ior(const DSc
 }
 
 // (-DRTMI_CYCLES=2: the cycles of the closest-hit, shadow and container queries go to counters 0, 1, 2 - tools/cycles.py)
-template <typename R, int MODE, bool TREE>
+template <typename R, int MODE, int TREE>
 __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side, Hit<R> &best, R t_limit,
                          uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
 #if defined(RTMI_CYCLES) && RTMI_CYCLES == 2
@@ -1670,7 +1744,7 @@ __device__ __forceinline__ void traverse(const DScene<R> &sc, const Ray<R> &ray,
 // compute_refractive_indices (ray.rs:104-140) without the sorted list: a leaf is "open" in front of
 // the hit iff an odd number of its intersections precede the hit, and containers.last() is the open
 // leaf that was entered last (largest entry t).
-template <typename R, bool TREE>
+template <typename R, int TREE>
 __device__ __forceinline__ void collect_n1n2(const DScene<R> &sc, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
                                              const Hit<R> &h, Comps<R> &c, Stats &st) {
     Open<R> open;
@@ -1696,7 +1770,10 @@ template <typename R> struct Pending { // a refraction ray waiting for its turn 
 // entry laid out [entry][dword][lane] (conflict-free), 12 KB per wave = 12 waves per CU, which is the occupancy the
 // register budget allows anyway; deeper entries and the f64 validation mode use a per-lane array (scratch memory).
 // Recursion depth 5/6 scenes therefore push nothing to HBM.  One wave per workgroup (blockDim.x == 64) is assumed.
-constexpr int LDS_PEND = 4;      // flat scenes (a fifth pending ray - five refractions waiting at once, one per level of a depth-5 tree - goes to
+#ifndef RTMI_LDS_PEND
+#define RTMI_LDS_PEND 4
+#endif
+constexpr int LDS_PEND = RTMI_LDS_PEND; // flat scenes (a fifth pending ray - five refractions waiting at once, one per level of a depth-5 tree - goes to
                                  // scratch: rare, and the 2 KB are what the counter block and the pair tables live in; 12.3 KB per wave in all)
 constexpr int LDS_PEND_TREE = 4; // tree scenes share the 12 KB with the node stack (LDS_NODES); they do not stage the scene block
 constexpr uint32_t PEND_LEAF_BITS = 26, PEND_LEAF_MASK = (1u << PEND_LEAF_BITS) - 1u; // leaf | side << 26 | remaining << 27
@@ -1749,7 +1826,7 @@ template <typename R, int LP> struct PendingStack {
 };
 
 // World::is_shadowed (world.rs:172-180)
-template <typename R, bool TREE>
+template <typename R, int TREE>
 __device__ __forceinline__ bool is_shadowed(const DScene<R> &sc, const Incoming<R> &in, V3<R> p, uint32_t origin_leaf, uint32_t origin_side,
                                             Stats &st) {
     if (in.kind == IL_OMNI) return false;
@@ -1892,14 +1969,14 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
 // shade_hit is linear in its children's colours, so each ray carries the product of the factors
 // above it ("weight") and adds weight * (clipped direct light + emissive) to the sample.
 // PHOTON: the scene may carry a photon map (kernels of their own: the search's per-lane arrays are not for the others to pay)
-template <typename R, bool TREE, bool PHOTON = false>
+template <typename R, int TREE, bool PHOTON = false>
 __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
     const R EPS = (R)RTMI_EPSILON;
     V3<R> acc = mk<R>(0, 0, 0);
     R weight = (R)1;
     uint32_t origin_leaf = NONE, origin_side = 0;
     int cls = RTMI_STAT_PRIMARY;
-    constexpr int LP = TREE ? LDS_PEND_TREE : LDS_PEND;
+    constexpr int LP = TREE == KIND_TREE ? LDS_PEND_TREE : LDS_PEND;
     PendingStack<R, LP> pend;
     __shared__ uint32_t lds_pend[sizeof(R) == 4 ? LP : 1][8][64];
     bool first = true;

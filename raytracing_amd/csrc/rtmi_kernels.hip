@@ -108,11 +108,11 @@ __device__ __forceinline__ void stats_zero(Stats &s) {
 // on whole frames: flat scenes +7 ... +8.5 % with the block - chapter-11a 79.8 -> 86.4 Grays/s, the spills gone; tree scenes
 // -13 ... -20 % - a tree walk counts a node visit, box tests and leaf tests per step, and that many LDS atomics cost
 // more than the registers they free.  The photon-map kernels' LDS is full of candidate heaps.)
-template <typename R, bool TREE, bool PHOTON> __device__ __forceinline__ void stats_begin(Stats &s, int lane) {
+template <typename R, int TREE, bool PHOTON> __device__ __forceinline__ void stats_begin(Stats &s, int lane) {
 #ifndef RTMI_TREE_STATS_LDS
 #define RTMI_TREE_STATS_LDS 0
 #endif
-    if constexpr (sizeof(R) == 4 && !PHOTON && (!TREE || RTMI_TREE_STATS_LDS)) s.zero_in_lds(stats_block<TREE>(), TREE ? STAT_SLOTS_TREE : STAT_SLOTS_FLAT, lane);
+    if constexpr (sizeof(R) == 4 && !PHOTON && (TREE != KIND_TREE || RTMI_TREE_STATS_LDS)) s.zero_in_lds(stats_block<TREE>(), TREE == KIND_TREE ? STAT_SLOTS_TREE : STAT_SLOTS_FLAT, lane);
     else s.zero();
 #ifdef RTMI_CYCLES
     s.cyc[3] = 0ull - __builtin_readcyclecounter();
@@ -130,7 +130,7 @@ __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 }
 
 // One sample of Camera::multisample's loop body (camera.rs:274-276,283-285,292-296): sample 0 is the centred ray.
-template <typename R, bool TREE, bool PHOTON = false>
+template <typename R, int TREE, bool PHOTON = false>
 __device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<double> &cam, Rng &rng, Stats &st, int px, int py, uint32_t s) {
     rng_begin(rng, (uint32_t)(py * cam.hsize + px), s);
     st.inc(RTMI_STAT_SAMPLES);
@@ -240,8 +240,8 @@ __device__ __forceinline__ void keep_state(DPixelState<R> *__restrict__ state, s
 // out.  The others - a few per cent of the frame, needing anything from one to thousands of further samples - are
 // appended with their running sums to one of two work queues, by predicted need (variance / SE^2 - n): resample_kernel
 // then spreads them over the whole GPU instead of leaving each to the wave that owns its tile.
-template <typename R, bool TREE, bool SPREAD, bool PHOTON = false, bool DRAW = false>
-__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+template <typename R, int TREE, bool SPREAD, bool PHOTON = false, bool DRAW = false>
+__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
                                                     uint32_t wk_cap, DPixelState<R> *__restrict__ state) {
@@ -568,8 +568,8 @@ __global__ void __launch_bounds__(64) sum_up_kernel(DCamera<double> cam, float *
 // A pixel's samples are always summed in rounds of 64 (light: RTMI_LIGHT_ROUNDS rounds of 64 / RTMI_LIGHT_BATCH first)
 // counted from its own first-pass count, whoever computes them and however many were computed ahead: the image does
 // not depend on queue order, sharding, promotion or the prediction, bit for bit.
-template <typename R, bool TREE, bool PHOTON = false>
-__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
+template <typename R, int TREE, bool PHOTON = false>
+__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_TREE ? RTMI_WAVES_TREE : RTMI_WAVES) resample_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                       const DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
                                                       uint32_t *__restrict__ wk_final, uint32_t *__restrict__ wk_unit_pixel, uint32_t wk_cap,
@@ -703,8 +703,8 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
 // The units of pass `pass` (see resample_kernel): each wave pops batches of units, takes every unit's 64 samples and
 // leaves colours and counters in the unit's DChunk.
 constexpr int UNIT_BATCH_MAX = 16;
-template <typename R, bool TREE, bool PHOTON = false>
-__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
+template <typename R, int TREE, bool PHOTON = false>
+__global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
                                                    const DWorkItem<R> *__restrict__ wk_heavy, const uint32_t *__restrict__ wk_unit_pixel,
                                                    DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass) {
     stage_scene<R, TREE>(sc);
@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE ? RTMI_W
 // World::color_at for arbitrary rays + the IntersectionState of the first hit (rtmi_trace_rays).
 // TREE = false: the flat-scene code of the render kernels (LDS scene block, pair tables), for worlds whose objects are all
 // primitives - so that the known-answer tests and the host emulation go through the very loops the frames are rendered with.
-template <typename R, bool PHOTON = false, bool TREE = true>
+template <typename R, bool PHOTON = false, int TREE = KIND_TREE>
 __global__ void __launch_bounds__(64) trace_kernel(DScene<R> sc, uint32_t seed_lo, uint32_t seed_hi, long long n, const double *origins,
                                                    const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
     stage_scene<R, TREE>(sc); // (every lane of the wave, before any leaves)
@@ -837,12 +837,21 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
     const bool spread = rp.group > 1;
     const bool photon = sc.n_photons != 0; // (kernels of their own, tree kind, one lane per pixel: the host chooses tree = true, no spread)
     const bool draw = RTMI_DRAW_VISITS && !spread && wk.hdr != nullptr && grid_resample > 0; // (an open-ended call: its visits are long and uneven)
+    bool flatx = false; // a flat world with a transformed-sphere table: the KIND_FLATX kernels (f32 only)
+    if constexpr (sizeof(RTMI_REAL) == 4) flatx = !tree && !photon && (sc.xpair_counts & 255u) != 0u;
 #define RTMI_LAUNCH_RENDER(...) hipLaunchKernelGGL((render_kernel<RTMI_REAL, __VA_ARGS__>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state)
     if (photon && draw) RTMI_LAUNCH_RENDER(true, false, true, true);
     else if (photon) RTMI_LAUNCH_RENDER(true, false, true, false);
     else if (tree && spread) RTMI_LAUNCH_RENDER(true, true, false, false);
     else if (tree && draw) RTMI_LAUNCH_RENDER(true, false, false, true);
     else if (tree) RTMI_LAUNCH_RENDER(true, false, false, false);
+    else if (flatx) {
+        if constexpr (sizeof(RTMI_REAL) == 4) {
+            if (spread) RTMI_LAUNCH_RENDER(KIND_FLATX, true, false, false);
+            else if (draw) RTMI_LAUNCH_RENDER(KIND_FLATX, false, false, true);
+            else RTMI_LAUNCH_RENDER(KIND_FLATX, false, false, false);
+        }
+    }
     else if (spread) RTMI_LAUNCH_RENDER(false, true, false, false);
     else if (draw) RTMI_LAUNCH_RENDER(false, false, false, true);
     else RTMI_LAUNCH_RENDER(false, false, false, false);
@@ -855,11 +864,13 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
         if (pass > 0) {
             if (photon) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
             else if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            else if (flatx) { if constexpr (sizeof(RTMI_REAL) == 4) hipLaunchKernelGGL((units_kernel<RTMI_REAL, KIND_FLATX>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass); }
             else hipLaunchKernelGGL((units_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
             hipLaunchKernelGGL(sum_up_kernel<RTMI_REAL>, dim3(grid_resample), dim3(64), 0, st, cam, out, stats, wk.hdr, wk.heavy, wk.final_idx, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, state);
         } else {
             if (photon) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
             else if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
+            else if (flatx) { if constexpr (sizeof(RTMI_REAL) == 4) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, KIND_FLATX>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state); }
             else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
         }
     }
@@ -874,7 +885,7 @@ void launch_trace_kernel<RTMI_REAL>(int grid, const DScene<RTMI_REAL> &sc, uint3
                                     const double *origins, const double *dirs, const int *remaining, double *rgb, rtmi_hit_record *recs) {
     if (sc.n_photons) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, true>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
 #if RTMI_TRACE_FLAT
-    else if (staged_v<RTMI_REAL, false> && sc.root_child_count == 0) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
+    else if (staged_v<RTMI_REAL, KIND_FLATX> && sc.root_child_count == 0) hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false, KIND_FLATX>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
 #endif
     else hipLaunchKernelGGL((trace_kernel<RTMI_REAL, false>), dim3(grid), dim3(64), 0, 0, sc, seed_lo, seed_hi, n, origins, dirs, remaining, rgb, recs);
 }
