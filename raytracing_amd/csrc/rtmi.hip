@@ -148,6 +148,7 @@ template <typename R> struct DeviceArrays {
     DMaterial<R> *materials = nullptr;
     DPattern<R> *patterns = nullptr;
     DLight<R> *lights = nullptr;
+    DCsgLeaf *csg_leaf = nullptr;
 };
 
 // Work-queue memory of the adaptive second pass (rtmi_launch.hpp DWork): a per-device pool of up to WORK_SLOTS buffers.
@@ -324,7 +325,6 @@ struct rtmi_scene {
     DeviceArrays<double> f64;
     DNode *nodes = nullptr;
     DCsg *csgs = nullptr;
-    DGuard *csg_guard = nullptr;
     DChain *csg_chain = nullptr;
     DPhoton *photons = nullptr; // World::photon_map in kd-tree order
     uint32_t n_photons = 0;
@@ -440,6 +440,11 @@ struct Layout {
 
     std::vector<DGuard> guards() const {
         std::vector<DGuard> g(leaf_orig.size(), DGuard{0u, 0u});
+        // (two records for one leaf: the one with the weaker condition - the later `start` - stays)
+        auto put = [&g](uint32_t leaf, DGuard r) {
+            DGuard &o = g[leaf];
+            if (o.skip == 0u || r.start > o.start || (r.start == o.start && r.skip > o.skip)) o = r;
+        };
         for (size_t me = 0; me < csgs.size(); ++me) {
             const DCsg &c = csgs[me];
             if (c.op == (uint32_t)RTMI_NODE_CSG_UNION || c.left_end <= csg_l0[me] || csg_l2[me] <= c.left_end) continue;
@@ -449,7 +454,17 @@ struct Layout {
                 if (csgs[p].op == (uint32_t)RTMI_NODE_CSG_UNION || csg_l0[p] != csg_l0[top] || csgs[p].left_end != csg_l2[top]) break;
                 top = p;
             }
-            g[c.left_end - 1] = DGuard{csg_l0[me], csg_l2[top]};
+            put(c.left_end - 1, DGuard{csg_l0[me], csg_l2[top]});
+            // an Intersection is as empty when its RIGHT side gave the ray no root (a left root passes only while inr)
+            if (c.op == (uint32_t)RTMI_NODE_CSG_INTERSECTION) put(csg_l2[me] - 1, DGuard{c.left_end, csg_l2[top]});
+        }
+        // A record that can never fire is dropped (the leaf loop of csg_root works in runs that end at a record): one with
+        // an earlier record e' inside its own range whose range starts no earlier and whose jump goes at least as far - if
+        // e' fired, the ray is past this leaf; if it did not, the root that stopped it stops this one too.
+        for (size_t e = 0; e < g.size(); ++e) {
+            if (g[e].skip == 0u) continue;
+            for (size_t f = g[e].start; f < e; ++f)
+                if (g[f].skip != 0u && g[f].start >= g[e].start && g[f].skip >= g[e].skip) { g[e] = DGuard{0u, 0u}; break; }
         }
         return g;
     }
@@ -1082,6 +1097,31 @@ static std::vector<DPhoton> balance_photons(const rtmi_photon *ph, long long n) 
 }
 
 // what the flat f32 kernels stage in LDS (rtmi_device.hpp stage_scene) and the list that goes with it
+// Largest eigenvalue of F^T F for a 3x3 matrix F (row major): the square of F's largest singular value.  Closed form for a
+// symmetric 3x3 matrix (trigonometric solution of the characteristic cubic), never below the true value by more than rounding
+// (callers pad the radius they derive from it).
+static double largest_eigenvalue_ftf(const double F[9]) {
+    double A[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = F[i] * F[j] + F[3 + i] * F[3 + j] + F[6 + i] * F[6 + j];
+    const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+    if (p1 <= 1e-300) return std::max(A[0][0], std::max(A[1][1], A[2][2]));
+    const double p2 = (A[0][0] - q) * (A[0][0] - q) + (A[1][1] - q) * (A[1][1] - q) + (A[2][2] - q) * (A[2][2] - q) + 2.0 * p1;
+    const double p = std::sqrt(p2 / 6.0);
+    double B[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) B[i][j] = (A[i][j] - (i == j ? q : 0.0)) / p;
+    const double detB = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                        B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+    const double r = std::min(1.0, std::max(-1.0, 0.5 * detB));
+    const double lam = q + 2.0 * p * std::cos(std::acos(r) / 3.0);
+    double fro = 0; // (never above the Frobenius norm, never below a third of it: a guard against a bad cubic)
+    for (int k = 0; k < 9; ++k) fro += F[k] * F[k];
+    if (!(lam >= fro / 3.0 - 1e-12 * fro) || !(lam <= fro * (1.0 + 1e-12))) return fro;
+    return lam;
+}
+
 struct QuickTables {
     std::vector<uint32_t> quick, pairs, others;
     uint32_t pair_counts = 0, real_counts = 0, xpair_counts = 0;
@@ -1147,13 +1187,24 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
                 const double F[9] = {(f0 * r0 - g0 * q0) * id, (c0 * q0 - b0 * r0) * id, (b0 * g0 - c0 * f0) * id,
                                      (g0 * p0 - e0 * r0) * id, (a0 * r0 - c0 * p0) * id, (c0 * e0 - a0 * g0) * id,
                                      (e0 * q0 - f0 * p0) * id, (b0 * p0 - a0 * q0) * id, (a0 * f0 - b0 * e0) * id};
-                double fro = 0, cw[3];
-                for (int k = 0; k < 9; ++k) fro += F[k] * F[k];
+                double cw[3];
                 for (int k = 0; k < 3; ++k) {
                     const double x = co[0] - m[3], y = co[1] - m[7], z = co[2] - m[11]; // F (c_o - t)
                     cw[k] = F[3 * k] * x + F[3 * k + 1] * y + F[3 * k + 2] * z;
                 }
-                const double rw = std::sqrt(fro) * ro * (1.0 + 1e-4) + 1e-6;
+                // |F v| <= s |v| with s the largest singular value of F (a pip of a die - a sphere scaled by 0.2, 0.1, 0.2 -
+                // gets its longest half-axis, where the Frobenius norm gave 1.5 times that); a cube's corners are mapped one by one
+                double stretch = ro * std::sqrt(largest_eigenvalue_ftf(F));
+                if (s.kind == RTMI_CUBE) {
+                    stretch = 0;
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        const double x = (c8 & 1) ? 1.0 : -1.0, y = (c8 & 2) ? 1.0 : -1.0, z = (c8 & 4) ? 1.0 : -1.0;
+                        double d2 = 0;
+                        for (int k = 0; k < 3; ++k) { const double w = F[3 * k] * x + F[3 * k + 1] * y + F[3 * k + 2] * z; d2 += w * w; }
+                        stretch = std::max(stretch, std::sqrt(d2));
+                    }
+                }
+                const double rw = stretch * (1.0 + 1e-4) + 1e-6;
                 if (std::isfinite(rw) && std::isfinite(cw[0]) && std::isfinite(cw[1]) && std::isfinite(cw[2])) {
                     for (int k = 0; k < 3; ++k) g.fast[k] = (R)cw[k];
                     g.fast[3] = (R)(rw * rw);
@@ -1307,7 +1358,30 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
         l.inv_up2 = (R)(u2 > 0 ? 1.0 / u2 : 0.0); l.inv_right2 = (R)(r2 > 0 ? 1.0 / r2 : 0.0);
         l.kind = s.kind;
     }
+    // DCsgLeaf records (rtmi_device.hpp): what csg_root's first pass over a run of leaves needs of each, 32 bytes a leaf
+    std::vector<DCsgLeaf> cleaf(leaves.size());
+    {
+        const std::vector<DGuard> gd = L.guards();
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            DCsgLeaf &c = cleaf[i];
+            memset(&c, 0, sizeof c);
+            c.kind = leaves[i].kind;
+            for (int a = 0; a < 3; ++a) c.c[a] = (leaves[i].kind & LEAF_BOUND) ? (float)leaves[i].fast[a] : 0.0f;
+            c.r2 = (leaves[i].kind & LEAF_BOUND) ? (float)leaves[i].fast[3] : -1.0f;
+            c.gstart = gd[i].start; c.gskip = gd[i].skip;
+        }
+        for (const DNode &nd : L.nodes) {
+            if (!(nd.flags & NODE_CSGROOT)) continue;
+            // run: the leaves from this one to the next guard record (or the end of the root), CSG_RUN at most
+            uint32_t run = 0;
+            for (uint32_t i = nd.leaf_first + nd.leaf_count; i-- > nd.leaf_first;) {
+                run = (cleaf[i].gskip != 0u || run >= (uint32_t)CSG_RUN) ? 1u : run + 1u;
+                cleaf[i].run = run;
+            }
+        }
+    }
     int rc;
+    if ((rc = upload(&A.csg_leaf, cleaf)) != RTMI_OK) return rc;
     if ((rc = upload(&A.leaves, leaves)) != RTMI_OK) return rc;
     if ((rc = upload(&A.tris, tris)) != RTMI_OK) return rc;
     if ((rc = upload(&A.materials, mats)) != RTMI_OK) return rc;
@@ -1318,7 +1392,7 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
 
 template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_desc *d, const Layout &L, const DeviceArrays<R> &A, DScene<R> &h) {
     h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
-    h.nodes = s->nodes; h.csgs = s->csgs; h.csg_guard = s->csg_guard; h.csg_chain = s->csg_chain;
+    h.nodes = s->nodes; h.csgs = s->csgs; h.csg_leaf = A.csg_leaf; h.csg_chain = s->csg_chain;
     h.photons = s->n_photons ? s->photons : nullptr; h.n_photons = s->n_photons; h.n_nearest = s->n_photons ? (uint32_t)d->n_nearest : 0u;
     h.no_direct = d->no_direct_illumination ? 1u : 0u; h.pad3 = 0;
     h.photon_radius = d->max_search_radius > 0.0 ? (R)d->max_search_radius : (R)INFINITY; h.leaf_orig = s->leaf_orig;
@@ -1407,9 +1481,9 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (!s) return;
     int prev = -1;
     if (hipGetDevice(&prev) == hipSuccess && s->device >= 0 && prev != s->device) (void)hipSetDevice(s->device);
-    (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights);
-    (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights);
-    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_guard); (void)hipFree(s->csg_chain); (void)hipFree(s->photons); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->pairs); (void)hipFree(s->others); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
+    (void)hipFree(s->f32.leaves); (void)hipFree(s->f32.tris); (void)hipFree(s->f32.materials); (void)hipFree(s->f32.patterns); (void)hipFree(s->f32.lights); (void)hipFree(s->f32.csg_leaf);
+    (void)hipFree(s->f64.leaves); (void)hipFree(s->f64.tris); (void)hipFree(s->f64.materials); (void)hipFree(s->f64.patterns); (void)hipFree(s->f64.lights); (void)hipFree(s->f64.csg_leaf);
+    (void)hipFree(s->nodes); (void)hipFree(s->csgs); (void)hipFree(s->csg_chain); (void)hipFree(s->photons); (void)hipFree(s->leaf_orig); (void)hipFree(s->wtris); (void)hipFree(s->quick); (void)hipFree(s->pairs); (void)hipFree(s->others); (void)hipFree(s->bvh2); (void)hipFree(s->btris);
     host_cache_free(s->host_cache);
     multi_cache_free(s->multi_cache, s->device);
     (void)hipSetDevice(s->device);
@@ -1459,7 +1533,6 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->bvh2, bvh2);
     if (rc == RTMI_OK) rc = upload(&s->btris, btris);
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
-    if (rc == RTMI_OK) rc = upload(&s->csg_guard, L.guards());
     if (rc == RTMI_OK) rc = upload(&s->csg_chain, L.chains());
     if (rc == RTMI_OK && desc->n_photons > 0) { s->n_photons = (uint32_t)desc->n_photons; rc = upload(&s->photons, balance_photons(desc->photons, desc->n_photons)); }
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);

@@ -159,6 +159,17 @@ struct DCsg { // 16 B
 // that is no Union either.  A die of chapter-16 is ((((((cube & sphere) - side) - side) ...): a ray that misses the cube
 // is done with the die after one test instead of 23.
 struct DGuard { uint32_t start, skip; }; // skip == 0: no record at this leaf
+// A leaf below a CSG root as the FIRST pass of csg_root's leaf loop reads it (one 32-byte scalar load, the loads of a run of
+// leaves all in flight together): the leaf's bounding sphere (f32 scenes; r2 < 0: none), its kind word, its guard record,
+// and `run` - the leaves from this one up to and including the next that has a guard record (or the root's last), CSG_RUN
+// at most.  Inside a run no jump can start, so whether a lane tests a leaf of it is known when the run begins.
+struct alignas(32) DCsgLeaf {
+    float c[3], r2;
+    uint32_t kind;
+    uint32_t gstart, gskip; // DGuard
+    uint32_t run;
+};
+constexpr int CSG_RUN = 32; // (a bit per leaf in a 32-bit word)
 // A leaf's CSG ancestors as two masks over the root's operator flags (bit 2b = inl, 2b + 1 = inr of operator b): the flags
 // CsgOp::eval (csg.rs:26-32) needs clear / set for a root of this leaf to pass (see csg_root).
 struct alignas(16) DChain { unsigned long long zero, one; };
@@ -180,7 +191,7 @@ template <typename R> struct DScene {
     const DLight<R> *lights;
     const DNode *nodes;
     const DCsg *csgs;
-    const DGuard *csg_guard;   // one per leaf
+    const DCsgLeaf *csg_leaf;  // one per leaf (those below CSG roots are filled in)
     const DChain *csg_chain;   // one per leaf
     const DPhoton *photons;    // World::photon_map in kd-tree order (node i: children 2i + 1, 2i + 2), or null
     uint32_t n_photons, n_nearest, no_direct, pad3;
@@ -492,6 +503,13 @@ __device__ __forceinline__ void stats_sample_end(Stats &st) { st.flops += st.fl;
 #define CYC4_BEGIN(v)
 #define CYC4_END(st, i, v)
 #endif
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 5 // 5: csg_root's bound pass over a run, its full leaf tests, its sort + filter
+#define CYC5_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CYC5_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
+#else
+#define CYC5_BEGIN(v)
+#define CYC5_END(st, i, v)
+#endif
 #if defined(RTMI_CYCLES) && RTMI_CYCLES == 1
 #define CYC_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
 #define CYC_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
@@ -695,7 +713,13 @@ template <typename R> __device__ __forceinline__ bool line_misses_sphere(const R
 //  * smooth triangles: the push is along the INTERPOLATED normal, so a ray may start on one side of the flat
 //    triangle and head for the other (the reference's shadow-terminator artefact, which must be kept): the root is
 //    in front iff the ray travels towards the plane, i.e. sign(d . n_g) differs from the side it started on.
-template <typename R>
+// What a leaf that its bounding sphere ruled out is priced at: the reference's own (missing) test of it.
+__device__ __forceinline__ uint32_t bound_reject_flops(uint32_t gkind) {
+    const uint32_t kind = gkind & LEAF_KIND_MASK;
+    return kind == RTMI_SPHERE ? F_SPHERE_MISS : kind == RTMI_CUBE ? F_CUBE : kind >= RTMI_TRIANGLE ? F_TRI_U : (gkind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
+}
+// BOUND_DONE: the caller has tested the leaf's bounding sphere already (csg_root's first pass)
+template <typename R, bool BOUND_DONE = false>
 __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, uint32_t gkind, const DTri<R> *tris, const Ray<R> &ray, bool is_origin, uint32_t origin_side,
                                           R t[4], R &u, R &v, Stats &st) {
     // (gkind = g.kind, handed in by callers that know it already - the top-level loop has it from the leaf's LDS record -
@@ -719,10 +743,8 @@ __device__ __forceinline__ int leaf_roots(const DLeaf<R> &g, uint32_t gkind, con
             n = 2;
             fl = F_SPHERE_HIT;
         }
-    } else if (sizeof(R) == 4 && (gkind & LEAF_BOUND) && !is_origin && line_misses_sphere(ray, g.fast)) {
-        // no roots; priced like the reference's own (missing) test of this leaf
-        fl = kind == RTMI_SPHERE ? F_SPHERE_MISS : kind == RTMI_CUBE ? F_CUBE : kind >= RTMI_TRIANGLE ? F_TRI_U
-             : (gkind & LEAF_CLOSED) ? F_CYL_CLOSED : F_CYL_OPEN;
+    } else if (sizeof(R) == 4 && !BOUND_DONE && (gkind & LEAF_BOUND) && !is_origin && line_misses_sphere(ray, g.fast)) {
+        fl = bound_reject_flops(gkind); // no roots
     } else if (kind == RTMI_PLANE) { // plane.rs:35-44 needs the y row of the object-space ray only
         const R oy = g.inv[4] * ray.o.x + g.inv[5] * ray.o.y + g.inv[6] * ray.o.z + g.inv[7];
         const R dy = g.inv[4] * ray.d.x + g.inv[5] * ray.d.y + g.inv[6] * ray.d.z;
@@ -809,54 +831,18 @@ template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op
     if (leaf != hit_leaf && (op.other == NONE || t_entry > op.other_t)) { op.other = leaf; op.other_t = t_entry; }
 }
 
-// The intersections csg_root buffers, per lane: scratch memory.  -DRTMI_CSG_LDS=n keeps the first n of them in LDS
-// ([entry][lane]) instead; measured on the dice frame (a ray that hits a die has 4 to 8): n = 0 333 ms, 4 345 ms, 8 380 ms -
-// the per-lane scratch lines stay in the vector cache, and LDS is what the pending-ray stacks need.
-#ifndef RTMI_CSG_LDS
-#define RTMI_CSG_LDS 0
-#endif
-constexpr int CSG_LDS = RTMI_CSG_LDS;
+// The intersections csg_root buffers, per lane: scratch memory.  (Keeping the first 4 or 8 of them in LDS, [entry][lane],
+// was measured on the dice frame: 333 ms without, 345 and 380 ms with - the per-lane scratch lines stay in the vector cache,
+// and LDS is what the pending-ray stacks need.  Nor did reading up to eight of them into registers in one batch before the
+// filter, with every leaf's DChain packed into one word beside them, change the frame's time: 196.4 and 200.9 ms against
+// 196.0 - the filter's time is its own arithmetic and branches, not the waits for the buffer.)
 template <typename R> struct CsgBuf {
-    static constexpr int IN_LDS = sizeof(R) == 4 ? CSG_LDS : 0;
-    R deep_t[CSG_BUF - IN_LDS];
-    uint32_t deep_id[CSG_BUF - IN_LDS];
-    uint32_t (*lds)[CSG_LDS > 0 ? CSG_LDS : 1][64];
-    int lane;
-    __device__ __forceinline__ CsgBuf() {
-        if constexpr (IN_LDS > 0) {
-            __shared__ uint32_t s_csg[2][CSG_LDS > 0 ? CSG_LDS : 1][64]; // t bits, id
-            lds = s_csg;
-        } else lds = nullptr;
-#ifdef RTMI_HOST_EMUL
-        lane = 0;
-#else
-        lane = threadIdx.x & 63;
-#endif
-    }
-    __device__ __forceinline__ void put(int i, R t, uint32_t id) {
-        if constexpr (IN_LDS > 0) {
-            if (i < CSG_LDS) { lds[0][i][lane] = __builtin_bit_cast(uint32_t, t); lds[1][i][lane] = id; return; }
-        }
-        deep_t[i - IN_LDS] = t; deep_id[i - IN_LDS] = id;
-    }
-    __device__ __forceinline__ R t(int i) const {
-        if constexpr (IN_LDS > 0) {
-            if (i < CSG_LDS) return __builtin_bit_cast(R, lds[0][i][lane]);
-        }
-        return deep_t[i - IN_LDS];
-    }
-    __device__ __forceinline__ uint32_t id(int i) const {
-        if constexpr (IN_LDS > 0) {
-            if (i < CSG_LDS) return lds[1][i][lane];
-        }
-        return deep_id[i - IN_LDS];
-    }
-    __device__ __forceinline__ void set_id(int i, uint32_t id) {
-        if constexpr (IN_LDS > 0) {
-            if (i < CSG_LDS) { lds[1][i][lane] = id; return; }
-        }
-        deep_id[i - IN_LDS] = id;
-    }
+    R deep_t[CSG_BUF];
+    uint32_t deep_id[CSG_BUF];
+    __device__ __forceinline__ void put(int i, R t, uint32_t id) { deep_t[i] = t; deep_id[i] = id; }
+    __device__ __forceinline__ R t(int i) const { return deep_t[i]; }
+    __device__ __forceinline__ uint32_t id(int i) const { return deep_id[i]; }
+    __device__ __forceinline__ void set_id(int i, uint32_t id) { deep_id[i] = id; }
 };
 
 // Evaluate one CSG root (CsgPair::intersect + filter_intersections, csg.rs:97-124, recursively):
@@ -872,11 +858,37 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
     CYC_BEGIN(c_leaf);
     const uint32_t leaf_end = leaf_first + leaf_count;
     uint32_t skip_until = leaf_first, last_root = NONE; // leaves below skip_until are not tested (DGuard); the last leaf that had a root
-    for (uint32_t li = leaf_first; li < leaf_end; ++li) {
-        const DLeaf<R> &g = sc.leaves[li];
-        if (li >= skip_until && !(MODE == MODE_ANY && !(g.kind & LEAF_CAST_SHADOW))) {
+    // The leaves in runs (DCsgLeaf): a first pass tests the ray's line against the bounding sphere of every leaf of the run -
+    // short records through scalar loads that do not wait for each other, a dozen operations a leaf - and the second pass
+    // goes through the full test of only those leaves that some lane of the wave still needs.  (A ray through a die of
+    // chapter-16 passes the spheres of two or three of its 21 dimples.)
+    for (uint32_t base = leaf_first; base < leaf_end;) {
+        uint32_t run = sc.csg_leaf[base].run;
+        run = min(run == 0u ? 1u : run, min((uint32_t)CSG_RUN, leaf_end - base));
+        uint32_t near = 0u, visit = 0u; // per lane: leaves to test in full; wave: leaves some lane tests in full
+        CYC5_BEGIN(c_p1);
+#pragma unroll 4
+        for (uint32_t b = 0; b < run; ++b) {
+            const DCsgLeaf &c = sc.csg_leaf[base + b];
+            const uint32_t li = base + b, ckind = c.kind;
+            const bool test = li >= skip_until && !(MODE == MODE_ANY && !(ckind & LEAF_CAST_SHADOW));
+            bool out = false;
+            if constexpr (sizeof(R) == 4) out = (ckind & LEAF_BOUND) != 0u && li != origin_leaf && line_misses_sphere(ray, c.c);
+            if (test && out) { st.inc(RTMI_STAT_LEAF_TESTS); st.fl += F_XFORM + bound_reject_flops(ckind); }
+            const bool full = test && !out;
+            near |= full ? 1u << b : 0u;
+            visit |= __ballot(full) != 0ull ? 1u << b : 0u;
+        }
+        CYC5_END(st, 0, c_p1);
+        CYC5_BEGIN(c_p2);
+        while (visit != 0u) {
+            const uint32_t b = (uint32_t)__builtin_ctz(visit);
+            visit &= visit - 1u;
+            if (!((near >> b) & 1u)) continue;
+            const uint32_t li = base + b;
+            const DLeaf<R> &g = sc.leaves[li];
             R t[4], u, v;
-            int n = leaf_roots(g, g.kind, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
+            int n = leaf_roots<R, true>(g, g.kind, sc.tris, ray, li == origin_leaf, origin_side, t, u, v, st);
             if (n > 0) last_root = li;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -890,12 +902,15 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
                 }
             }
         }
-        const DGuard gd = sc.csg_guard[li];
-        if (gd.skip != 0 && li + 1 >= skip_until && (last_root == NONE || last_root < gd.start)) skip_until = max(skip_until, gd.skip);
-        if (__ballot(skip_until < leaf_end) == 0) break; // every lane that is here is done with this root
+        CYC5_END(st, 1, c_p2);
+        const DCsgLeaf &e = sc.csg_leaf[base + run - 1u];
+        base += run;
+        if (e.gskip != 0u && base >= skip_until && (last_root == NONE || last_root < e.gstart)) skip_until = max(skip_until, e.gskip);
+        if (__ballot(skip_until < leaf_end) == 0ull) break; // every lane that is here is done with this root
     }
     CYC_END(st, 1, c_leaf);
     CYC_BEGIN(c_sort);
+    CYC5_BEGIN(c_sort5);
     // filter_intersections (csg.rs:107-124) for a root of leaf li, all its CSG ancestors at once.  CsgOp::eval depends, for
     // a given operator and side, on ONE of the operator's two flags (a left root on inr, a right root on inl), so "passes
     // every ancestor" is: the flags in chain.zero are clear and those in chain.one are set (DChain, built on the host).
@@ -945,6 +960,7 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
         }
     }
     CYC_END(st, 2, c_sort);
+    CYC5_END(st, 2, c_sort5);
     if (MODE == MODE_COLLECT) {
         // survivors in front of the hit, per leaf: odd count = still open, entered at its last such root
         for (int i = 0; i < k; ++i) {
