@@ -830,9 +830,11 @@ struct UnitBvhBuilder {
         out2.emplace_back();
         DBvh2 rec;
         memset(&rec, 0, sizeof rec);
-        for (int a = 0; a < 3; ++a) {
-            rec.lo0[a] = bin[n.left].b.lo[a]; rec.hi0[a] = bin[n.left].b.hi[a];
-            rec.lo1[a] = bin[n.right].b.lo[a]; rec.hi1[a] = bin[n.right].b.hi[a];
+        const Box *cb[2] = {&bin[n.left].b, &bin[n.right].b};
+        for (int c = 0; c < 2; ++c) {
+            rec.lox[c] = cb[c]->lo[0]; rec.hix[c] = cb[c]->hi[0];
+            rec.loy[c] = cb[c]->lo[1]; rec.hiy[c] = cb[c]->hi[1];
+            rec.loz[c] = cb[c]->lo[2]; rec.hiz[c] = cb[c]->hi[2];
         }
         rec.child[0] = emit2(n.left, d + 1);
         rec.child[1] = emit2(n.right, d + 1);
@@ -1279,7 +1281,8 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
                 std::vector<uint32_t> &xg = xgroup[(kind & LEAF_CAST_SHADOW) ? 0 : 1];
                 // (room: LDS_XPAIRS records for both groups, each rounded up to whole pairs)
                 const size_t pairs_if = (xgroup[0].size() + (&xg == &xgroup[0] ? 1 : 0) + 1) / 2 + (xgroup[1].size() + (&xg == &xgroup[1] ? 1 : 0) + 1) / 2;
-                if (affine && pairs_if <= (size_t)LDS_XPAIRS) { xg.push_back((uint32_t)i); (*quick)[i * QUICK_DW] = kind | LEAF_XPAIR; continue; }
+                // (a world with Groups, CSG or meshes runs the KIND_TREE kernels, which hold no transformed-sphere table)
+                if (affine && pairs_if <= (size_t)LDS_XPAIRS && L.nodes[0].child_count == 0) { xg.push_back((uint32_t)i); (*quick)[i * QUICK_DW] = kind | LEAF_XPAIR; continue; }
             }
             if (!(kind & LEAF_QUICK)) { qt->others.push_back((uint32_t)i); continue; }
             group[((kind & LEAF_FAST) ? 0 : 2) + ((kind & LEAF_CAST_SHADOW) ? 0 : 1)].push_back((uint32_t)i);

@@ -122,7 +122,7 @@ struct DWTri { // 48 B
 // nodes they need is close to what each needs alone; and a traversal without per-lane stacks, vector loads or
 // divergent branches is what this machine runs well.
 struct alignas(64) DBvh2 { // 64 B
-    float lo0[3], hi0[3], lo1[3], hi1[3]; // the two children's bounds
+    float lox[2], hix[2], loy[2], hiy[2], loz[2], hiz[2]; // the two children's bounds, a plane of both at a time (slab_pair)
     uint32_t child[2];                     // stack entries (ENT_BVH | node, ENT_TRIS | count - 1 << 26 | first triangle)
     uint32_t pad[2];
 };
@@ -241,6 +241,9 @@ template <typename R> struct DScene {
 // world that also has spheres under a general affine transform in the transformed-sphere table (a kernel of its own: the
 // table's loop holds 24 more registers, which cost the other flat scenes 8 % when it was compiled into their kernel).
 enum { KIND_FLAT = 0, KIND_TREE = 1, KIND_FLATX = 2 };
+// (The tree kernels with the block staged as well - pair tables for the top-level spheres and planes, materials and lights
+// from LDS - were measured in round 3: teapot 23.7 -> 25.5 ms, dice 196 -> 206 ms; the second code path costs them 16 to 28
+// more spilled registers, and that outweighs the scalar loads it saves.)
 template <typename R, int TREE> constexpr bool staged_v = sizeof(R) == 4 && TREE != KIND_TREE;
 constexpr int LDS_QUICK = 16, LDS_PATS = 4, LDS_MATS = 16, LDS_LIGHTS = 4;
 constexpr int QUICK_DW = 8;
@@ -509,6 +512,13 @@ __device__ __forceinline__ void stats_sample_end(Stats &st) { st.flops += st.fl;
 #else
 #define CYC5_BEGIN(v)
 #define CYC5_END(st, i, v)
+#endif
+#if defined(RTMI_CYCLES) && RTMI_CYCLES == 6 // 6: packet_tris - its box-pair steps, its triangle runs, its pops
+#define CYC6_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CYC6_END(st, i, v) (st).cyc[i] += __builtin_readcyclecounter() - v
+#else
+#define CYC6_BEGIN(v)
+#define CYC6_END(st, i, v)
 #endif
 #if defined(RTMI_CYCLES) && RTMI_CYCLES == 1
 #define CYC_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
@@ -1257,23 +1267,48 @@ __device__ __forceinline__ void tri_leaf(const DWTri &w, uint32_t li, const Ray<
 // A lane tests a node's child boxes only if it hit the node itself - exactly the tests it would make walking alone,
 // which is also what the counters count - and a subtree is entered if any lane's ray can still find a root in it.
 // ---------------------------------------------------------------------------------------------
+#ifdef RTMI_HOST_EMUL
+inline bool lanes_of(unsigned long long mask) { return mask & 1ull; } // (a wave of one)
+#else
+__device__ __forceinline__ bool lanes_of(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+#endif
 __device__ __forceinline__ uint32_t (*lds_packet_stack())[PACKET_STACK] {
     __shared__ uint32_t s_packet[3][PACKET_STACK]; // entry, mask low, mask high
     return s_packet;
 }
-__device__ __forceinline__ bool slab2(const float *lo, const float *hi, const Ray<float> &ray, V3<float> inv_d, float t_lo, float t_hi, float &tnear) {
-    // (NaN-ignoring min / max: a ray that runs inside a slab's boundary plane counts as inside the slab)
-    const float x0 = (lo[0] - ray.o.x) * inv_d.x, x1 = (hi[0] - ray.o.x) * inv_d.x;
-    const float y0 = (lo[1] - ray.o.y) * inv_d.y, y1 = (hi[1] - ray.o.y) * inv_d.y;
-    const float z0 = (lo[2] - ray.o.z) * inv_d.z, z1 = (hi[2] - ray.o.z) * inv_d.z;
-    const float tmin = max_(max_(min_(x0, x1), min_(y0, y1)), min_(z0, z1));
-    const float tmax = min_(min_(max_(x0, x1), max_(y0, y1)), max_(z0, z1));
-    tnear = tmin;
-    return tmin <= tmax && tmin <= t_hi && tmax >= t_lo;
+// What the box tests of a DBvh2 walk need of a ray, once per query: a slab plane's parameter is fma(plane, id, b) with
+// id = 1 / d and b = -o / d.  An axis the ray does not move along (|d| < 1e-30) gets id = 0, b = NaN: its parameters are all
+// NaN, the NaN-ignoring min / max below drop them, and the axis rules no box out - such a ray enters some boxes beside it
+// that Aabb::intersect (aabb.rs:45-70) would not; what it HITS is decided by the leaves, as ever.  e bounds the rounding of
+// the fma form (|b| 2^-24 per plane from b's own rounding, as much again from the sum) so that a box is never missed for it.
+struct RaySlab { float idx, idy, idz, bx, by, bz, e; };
+__device__ __forceinline__ RaySlab ray_slab(const Ray<float> &ray) {
+    RaySlab r;
+    const bool zx = !(abs_(ray.d.x) >= 1e-30f), zy = !(abs_(ray.d.y) >= 1e-30f), zz = !(abs_(ray.d.z) >= 1e-30f);
+    const float nan = __builtin_nanf("");
+    r.idx = zx ? 0.0f : rcp_(ray.d.x); r.idy = zy ? 0.0f : rcp_(ray.d.y); r.idz = zz ? 0.0f : rcp_(ray.d.z);
+    r.bx = zx ? nan : -ray.o.x * r.idx; r.by = zy ? nan : -ray.o.y * r.idy; r.bz = zz ? nan : -ray.o.z * r.idz;
+    r.e = ((zx ? 0.0f : abs_(r.bx)) + (zy ? 0.0f : abs_(r.by)) + (zz ? 0.0f : abs_(r.bz))) * 0x1p-22f;
+    return r;
+}
+// Both children's boxes of a DBvh2 node against one ray (aabb.rs:45-70,130-141): six packed multiply-adds give the twelve
+// plane parameters (the record holds a plane of both boxes side by side: one scalar register pair per instruction), then
+// per box 6 min / max, a max3 and a min3, the slack and the clamp to the ray's interval.  t0 / t1: where the ray enters.
+__device__ __forceinline__ void slab_pair(const DBvh2 &n, const RaySlab &rs, float t_lo, float t_hi, bool &h0, bool &h1, float &t0, float &t1) {
+    const f2 ix = splat2(rs.idx), iy = splat2(rs.idy), iz = splat2(rs.idz), bx = splat2(rs.bx), by = splat2(rs.by), bz = splat2(rs.bz);
+    const f2 lx = mk2(n.lox[0], n.lox[1]) * ix + bx, hx = mk2(n.hix[0], n.hix[1]) * ix + bx;
+    const f2 ly = mk2(n.loy[0], n.loy[1]) * iy + by, hy = mk2(n.hiy[0], n.hiy[1]) * iy + by;
+    const f2 lz = mk2(n.loz[0], n.loz[1]) * iz + bz, hz = mk2(n.hiz[0], n.hiz[1]) * iz + bz;
+    const float near0 = max_(max_(min_(lx.x, hx.x), min_(ly.x, hy.x)), min_(lz.x, hz.x));
+    const float far0 = min_(min_(max_(lx.x, hx.x), max_(ly.x, hy.x)), max_(lz.x, hz.x)) + rs.e;
+    const float near1 = max_(max_(min_(lx.y, hx.y), min_(ly.y, hy.y)), min_(lz.y, hz.y));
+    const float far1 = min_(min_(max_(lx.y, hx.y), max_(ly.y, hy.y)), max_(lz.y, hz.y)) + rs.e;
+    t0 = max_(near0, t_lo); t1 = max_(near1, t_lo);
+    h0 = t0 <= min_(far0, t_hi); h1 = t1 <= min_(far1, t_hi);
 }
 // UNITS: entries other than DBvh2 nodes and triangle runs can occur (a scene of meshes only runs the loop without them)
 template <int MODE, bool UNITS>
-__device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t root, bool mine, int base, const Ray<float> &ray, V3<float> inv_d, uint32_t origin_leaf,
+__device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t root, bool mine, int base, const Ray<float> &ray, const RaySlab &rs, uint32_t origin_leaf,
                             uint32_t origin_side, Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
     // (base: the entries of the shared stack below it belong to the caller, packet_scene)
     uint32_t (*stk)[PACKET_STACK] = lds_packet_stack();
@@ -1286,29 +1321,33 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
     // its ray hit nothing - and a push nobody made would be popped as whatever the LDS held)
     const int writer = __ffsll((long long)__ballot(true)) - 1;
     uint32_t cur = root;
+    uint32_t nv = 0; // box-pair steps of this lane: the counters get them on the way out (one add a step instead of three)
+    auto leave = [&]() { st.add(RTMI_STAT_NODE_VISITS, nv); st.add(RTMI_STAT_AABB_TESTS, 2u * nv); st.fl += nv * (2u * F_AABB); };
     unsigned long long mask = __ballot(mine);
     int sp = base;
     const float lo = (MODE == MODE_COLLECT) ? -Lim<float>::inf() : 0.0f;
     for (;;) {
-        const bool in = (mask >> lane) & 1ull;
+        const bool in = lanes_of(mask); // (the mask is wave-uniform: it becomes the execution mask as it is)
         bool pop = false;
         if ((cur & ENT_KIND) == ENT_TRIS) {
             const uint32_t first = cur & ENT_TRI_FIRST_MASK, count = ((cur >> ENT_TRI_FIRST_BITS) & 15u) + 1u;
             if (first + count > sc.n_btris) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: an entry that is not the builder's must not become an address)
+            CYC6_BEGIN(c_tri);
             if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
                 for (uint32_t i = 0; i < count; ++i) {
                     const DWTri &w = sc.btris[first + i]; // (wave-uniform index: a scalar load)
                     tri_leaf<MODE>(w, w.pad, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
                 }
             }
-            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return; // every ray of the wave is shadowed
+            CYC6_END(st, 1, c_tri);
+            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) { leave(); return; } // every ray of the wave is shadowed
             pop = true;
         } else if (UNITS && (cur & ENT_KIND) == ENT_LEAF) { // a primitive that is not a triangle
             const uint32_t li = cur & ~ENT_KIND;
             if (li >= sc.n_leaves) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: see above)
             if (in && !(MODE == MODE_ANY && best.leaf != NONE))
                 plain_leaf<float, MODE>(sc, li, sc.leaves[li], sc.leaves[li].kind, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
-            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return;
+            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) { leave(); return; }
             pop = true;
         } else if (UNITS && (cur & ENT_KIND) == 0u) { // a CSG root
             if (cur >= sc.n_nodes) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: see above)
@@ -1319,20 +1358,18 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
                 st.inc(RTMI_STAT_NODE_VISITS);
                 csg_root<float, MODE>(sc, leaf_first, leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             }
-            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) return;
+            if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) { leave(); return; }
             pop = true;
         } else {
             if ((cur & ENT_KIND) != ENT_BVH || (cur & ~ENT_KIND) >= sc.n_bvh2) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never: see above)
+            CYC6_BEGIN(c_box);
             const DBvh2 &n = sc.bvh2[cur & ~ENT_KIND];
             const float hi = (MODE == MODE_CLOSEST) ? best.t : t_limit;
             float t0 = 0, t1 = 0;
             bool h0 = false, h1 = false;
             if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
-                h0 = slab2(n.lo0, n.hi0, ray, inv_d, lo, hi, t0);
-                h1 = slab2(n.lo1, n.hi1, ray, inv_d, lo, hi, t1);
-                st.inc(RTMI_STAT_NODE_VISITS);
-                st.add(RTMI_STAT_AABB_TESTS, 2);
-                st.fl += 2 * F_AABB;
+                slab_pair(n, rs, lo, hi, h0, h1, t0, t1);
+                ++nv;
             }
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
             if ((m0 | m1) == 0ull) pop = true;
@@ -1350,12 +1387,15 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
                 cur = one_first ? n.child[1] : n.child[0];
                 mask = one_first ? m1 : m0;
             }
+            CYC6_END(st, 0, c_box);
         }
         if (pop) {
-            if (sp == base) return;
+            if (sp == base) { leave(); return; }
+            CYC6_BEGIN(c_pop);
             --sp;
             cur = __builtin_amdgcn_readfirstlane(stk[0][sp]);
             mask = (unsigned long long)__builtin_amdgcn_readfirstlane(stk[1][sp]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(stk[2][sp]) << 32);
+            CYC6_END(st, 2, c_pop);
         }
     }
 }
@@ -1375,6 +1415,7 @@ __device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<
 #endif
     const int writer = __ffsll((long long)__ballot(true)) - 1; // (see packet_tris)
     const V3<float> inv_d = mk<float>(rcp_(ray.d.x), rcp_(ray.d.y), rcp_(ray.d.z));
+    const RaySlab rs = ray_slab(ray);
     const float lo = (MODE == MODE_COLLECT) ? -Lim<float>::inf() : 0.0f;
     int sp = 0;
     auto push = [&](uint32_t v) {
@@ -1405,8 +1446,8 @@ __device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<
         if (flags & (NODE_TRIBVH | NODE_CSGROOT)) { // the node's own BVH, or the CSG root itself as a one-entry tree (its NODE_VISITS is counted there)
             if (h && (flags & NODE_CSGROOT)) st.add(RTMI_STAT_NODE_VISITS, 0xFFFFFFFFu);
             const uint32_t entry = (flags & NODE_TRIBVH) ? nd.csg_count : top;
-            if (sc.has_units) packet_tris<MODE, true>(sc, entry, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
-            else packet_tris<MODE, false>(sc, entry, h, sp, ray, inv_d, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            if (sc.has_units) packet_tris<MODE, true>(sc, entry, h, sp, ray, rs, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            else packet_tris<MODE, false>(sc, entry, h, sp, ray, rs, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             continue;
         }
         // children are popped first to last; sorted children (two, by centre along an axis) last to first when most of the
@@ -2269,13 +2310,13 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
         if (kind != PK_DIRECT && pt.direct_only) { alive = false; continue; }     // world.rs:228-232
         Hit<R> h = {Lim<R>::inf(), NONE, 0};
         Open<R> unused;
-        traverse<R, MODE_CLOSEST, true>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
+        traverse<R, MODE_CLOSEST, KIND_TREE>(sc, ray, origin_leaf, origin_side, h, Lim<R>::inf(), NONE, 0, unused, st);
         rays++;
         if (h.leaf != NONE && h.leaf >= sc.n_leaves) h.leaf = NONE; // (never: see color_at)
         if (h.leaf == NONE) { alive = false; continue; }
         Comps<R> c;
         uint32_t lkind, material;
-        prepare<R, true>(sc, ray, h, c, lkind, material);
+        prepare<R, KIND_TREE>(sc, ray, h, c, lkind, material);
         const DMaterial<R> m = sc.materials[material];
         V3<R> surface_color = ld3(m.color);
         if (m.pattern >= 0) surface_color = pattern_at(sc.patterns[m.pattern], xf_point(sc.leaves[h.leaf].inv, c.point));
@@ -2286,7 +2327,7 @@ __device__ __forceinline__ void trace_photons(const DScene<R> &sc, const DPhoton
         R pd_avg = dr_avg;
         const bool store = pd_avg > EPS;
         if (!pt.enable_diffuse) pd_avg = 0;
-        if (m.transparency > (R)0) collect_n1n2<R, true>(sc, ray, origin_leaf, origin_side, h, c, st); // (n1, n2 are read by schlick and refract only)
+        if (m.transparency > (R)0) collect_n1n2<R, KIND_TREE>(sc, ray, origin_leaf, origin_side, h, c, st); // (n1, n2 are read by schlick and refract only)
         if (m.reflective > (R)0 && m.transparency > (R)0) {
             const R r = schlick(c.eyev, c.normalv, c.n1, c.n2);
             spec *= r; trans *= (R)1 - r;

@@ -14,6 +14,8 @@ spawn = "spawn" in sys.argv  # a -DRTMI_CYCLES=4 build
 if spawn: sys.argv.remove("spawn")
 csg = "csg" in sys.argv  # a -DRTMI_CYCLES=5 build: csg_root's bound pass, its full leaf tests, its sort + filter
 if csg: sys.argv.remove("csg")
+tris = "tris" in sys.argv  # a -DRTMI_CYCLES=6 build: packet_tris' box-pair steps, triangle runs, pops
+if tris: sys.argv.remove("tris")
 shade = "shade" in sys.argv  # a -DRTMI_CYCLES=3 build: camera ray + Philox, prepare_computations + material + pattern, lighting()
 if shade: sys.argv.remove("shade")
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
@@ -31,6 +33,11 @@ for det in (True, False):
     if csg:
         a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
         print("%s %s: %.2f ms | of the kernels' wave cycles: csg_root bound pass %.1f %%, full leaf tests %.1f %%, sort + filter %.1f %%" % (
+            name, "1spp" if det else "shipped", st["kernel_ms"], 100 * a, 100 * b, 100 * c))
+        continue
+    if tris:
+        a, b, c = st["aabb_tests"] / tot, st["leaf_tests"] / tot, st["node_visits"] / tot
+        print("%s %s: %.2f ms | of the kernels' wave cycles: packet_tris box-pair steps %.1f %%, triangle runs %.1f %%, pops %.1f %%" % (
             name, "1spp" if det else "shipped", st["kernel_ms"], 100 * a, 100 * b, 100 * c))
         continue
     if shade:
