@@ -972,29 +972,24 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
     CYC_END(st, 2, c_sort);
     CYC5_END(st, 2, c_sort5);
     if (MODE == MODE_COLLECT) {
-        // survivors in front of the hit, per leaf: odd count = still open, entered at its last such root
+        // survivors in front of the hit, per leaf: odd count = still open, entered at its last such root.  A leaf's roots
+        // sit next to each other in the buffer, in ascending order (the leaf loop writes them so): one pass.
+        uint32_t cur = NONE, cnt = 0u;
+        R last_t = (R)0;
+        auto close_leaf = [&]() {
+            if (cnt == 0u) return;
+            if (cur == hit_leaf) open.hit_parity = cnt;
+            if (cnt & 1u) open_candidate(open, cur, hit_leaf, last_t);
+        };
         for (int i = 0; i < k; ++i) {
-            uint32_t id = buf.id(i);
+            const uint32_t id = buf.id(i), li = id & ID_LEAF_MASK;
+            if (li != cur) { close_leaf(); cur = li; cnt = 0u; }
             if (!(id & ID_KEEP)) continue;
-            uint32_t li = id & ID_LEAF_MASK, ord = (id >> ID_ORD_SHIFT) & 3u;
             const R ti = buf.t(i);
-            bool front = (li == hit_leaf) ? (ord < hit_ord) : (ti < t_limit);
-            if (!front) continue;
-            int cnt = 0;
-            bool last = true;
-            for (int j = 0; j < k; ++j) {
-                uint32_t jd = buf.id(j);
-                if (!(jd & ID_KEEP) || (jd & ID_LEAF_MASK) != li) continue;
-                uint32_t jo = (jd >> ID_ORD_SHIFT) & 3u;
-                bool jfront = (li == hit_leaf) ? (jo < hit_ord) : (buf.t(j) < t_limit);
-                if (!jfront) continue;
-                ++cnt;
-                if (jo > ord) last = false;
-            }
-            if (!last) continue;
-            if (li == hit_leaf) open.hit_parity = (uint32_t)cnt;
-            if (cnt & 1) open_candidate(open, li, hit_leaf, ti);
+            const bool front = (li == hit_leaf) ? (((id >> ID_ORD_SHIFT) & 3u) < hit_ord) : (ti < t_limit);
+            if (front) { ++cnt; last_t = ti; }
         }
+        close_leaf();
     }
 }
 
