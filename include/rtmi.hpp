@@ -559,6 +559,41 @@ inline const SceneItem &CsgPair::left() const { return items[0]; }
 inline const SceneItem &CsgPair::right() const { return items[1]; }
 
 inline Group group() { return Group(); }
+
+// TriangleMesh (triangle.rs:164-231): in the reference ONE Shape whose geometry is a list of flat faces - intersect() runs
+// intersect_triangle over every face and tags each root with the face's index (Intersection::i), normal_at() asks that
+// face.  The C ABI has no leaf kind for it: a mesh FLATTENS into a Group of RTMI_TRIANGLE leaves that share the Shape's
+// transform and material (into_group below), and build_bounding_tree may then split it like any Group - the same roots,
+// normals, colours and shadows, since a hit is decided triangle by triangle in the reference too.  What differs is object
+// IDENTITY, which the reference uses in two places: the n1 / n2 container list of a TRANSPARENT
+// mesh (ray.rs:111-140 toggles the one Shape on every face crossed; flattened, each face is a container of its own) and a
+// mesh as a CSG operand (csg.rs:102 `contains`: one shape there, one leaf per face here - the filter's in/out state is
+// per operand side, so the result is the same).  Opaque meshes, the only kind the reference's examples could build,
+// render identically; the `meshes` scene of raytracing_amd/scenes.py is the parity case.
+struct TriangleMesh {
+    std::vector<Shape> faces;
+    static TriangleMesh from_mesh(const std::vector<Point> &vertices, const std::vector<std::vector<size_t>> &triangles) { // triangle.rs:174-180
+        TriangleMesh m;
+        for (const auto &t : triangles) {
+            if (t.size() != 3) throw std::invalid_argument("TriangleMesh::from_mesh: a face is three vertex indices");
+            m.faces.push_back(triangle(vertices.at(t[0]), vertices.at(t[1]), vertices.at(t[2])));
+        }
+        return m;
+    }
+    bool aint_empty() const { return !faces.empty(); }                 // triangle.rs:182-184
+    void add_triangle(const Shape &tri) {                             // triangle.rs:186-188
+        if (tri.kind != RTMI_TRIANGLE) throw std::invalid_argument("TriangleMesh::add_triangle: flat triangles only");
+        faces.push_back(tri);
+    }
+    Shape get_triangle(size_t idx) const { return faces.at(idx); }     // triangle.rs:190-192
+    // Shape::new(mesh).with_material(m): the faces as a Group, every face with the mesh's material; the mesh's transform is
+    // the Group's (with_transform on the result)
+    Group into_group(const Phong &material) const {
+        Group g;
+        for (const Shape &f : faces) g.add_child(SceneItem(f.with_material(material)));
+        return g;
+    }
+};
 inline BoundingGroup bounding_group() { return BoundingGroup(); }
 inline CsgPair make_csg(CsgOp op, const SceneItem &a, const SceneItem &b) { CsgPair c; c.op = op; c.items = {a, b}; return c; }
 inline CsgPair csg_union(const SceneItem &a, const SceneItem &b) { return make_csg(CsgOp::Union, a, b); }

@@ -197,6 +197,12 @@ PYBIND11_MODULE(_front, m) {
         .def("cast_shadow", &CsgPair::cast_shadow).def("left", &CsgPair::left).def("right", &CsgPair::right)
         .def("aabb", &CsgPair::aabb).def_readonly("op", &CsgPair::op);
     m.def("group", &group);
+    py::class_<TriangleMesh>(m, "TriangleMesh")
+        .def(py::init<>()).def_static("new", []() { return TriangleMesh(); })
+        .def_static("from_mesh", &TriangleMesh::from_mesh)
+        .def("aint_empty", &TriangleMesh::aint_empty).def("add_triangle", &TriangleMesh::add_triangle)
+        .def("get_triangle", &TriangleMesh::get_triangle).def("into_group", &TriangleMesh::into_group)
+        .def("__len__", [](const TriangleMesh &t) { return t.faces.size(); });
     m.def("bounding_group", &bounding_group);
     m.def("csg_union", &csg_union);
     m.def("csg_intersection", &csg_intersection);

@@ -1668,7 +1668,8 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.n_visits = (uint32_t)visits;
     const int per_cu = (int)env_long("RTMI_GRID_PER_CU", (!spread && first_samples >= 4) ? RTMI_GRID_PER_CU_MANY : RTMI_GRID_PER_CU);
     int grid = (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * per_cu);
-    grid = std::max(std::min(grid, (int)((visits + 2) / 3)), (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * 12));
+    const long vpw = std::max(1l, env_long("RTMI_VISITS_PER_WAVE", 3));
+    grid = std::max(std::min(grid, (int)((visits + (unsigned long long)vpw - 1) / (unsigned long long)vpw)), (int)std::min<unsigned long long>(visits, (unsigned long long)s->num_cu * 12));
     bool f64 = o && o->precision == RTMI_PRECISION_F64;
     if (o && o->precision != RTMI_PRECISION_F32 && o->precision != RTMI_PRECISION_F64) return fail(RTMI_ERR_INVALID, "bad precision");
     const bool tree = s->h32.root_child_count != 0 || s->n_photons != 0; // (a photon map: the tree kind's kernels, which take flat scenes too)

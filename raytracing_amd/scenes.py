@@ -600,7 +600,52 @@ def photon_box_with_map(h=600, v=600, deterministic=False, n_photons=2_000_000, 
     return w, cam
 
 
-EXTRA_SCENES = {"photons": photon_room_with_map, "yard": yard, "photonbox": photon_box_with_map, "crowd": crowd}  # (bench.py --scene takes these too; not BASELINE configurations)
+def _icosahedron():
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    n = math.sqrt(1.0 + t * t)
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    return [rt.point(x / n, y / n, z / n) for (x, y, z) in v], [list(t3) for t3 in f]
+
+
+def meshes(h=300, v=150, deterministic=False):
+    """Not a reference example (none builds a TriangleMesh): the parity case of the flattened TriangleMesh (triangle.rs:164-231,
+    include/rtmi.hpp TriangleMesh) - an icosahedron mesh as a top-level Group, a second one, mirror
+    finished, under build_bounding_tree, an octahedron built face by face with add_triangle, and a mesh as the right side of
+    a CSG difference.  All opaque: the case in which a flattened mesh and the reference's one-Shape mesh render alike."""
+    w = rt.World.empty()
+    w.set_max_reflection_depth(4)
+    w.add_light(rt.AmbientLight(rt.color(0.08, 0.08, 0.08)))
+    w.add_light(rt.PointLight(rt.point(-6, 9, -7), rt.color(0.8, 0.8, 0.75)))
+    w.add_light(rt.PointLight(rt.point(5, 4, -6), rt.color(0.25, 0.25, 0.3)))
+    floor = rt.Phong.default().with_pattern(rt.checkers_pattern(rt.color(0.3, 0.3, 0.3), rt.color(0.75, 0.75, 0.7)).with_transform(
+        rt.translation(0.013, 0.0, 0.017))).with_diffuse(0.8).with_specular(0.1).with_reflective(0.15)
+    w.add_item(rt.plane().with_material(floor))
+    verts, faces = _icosahedron()
+    ico = rt.TriangleMesh.from_mesh(verts, faces)
+    red = rt.Phong.default().with_rgb(0.85, 0.25, 0.2).with_diffuse(0.7).with_specular(0.4).with_shininess(80.0)
+    w.add_item(ico.into_group(red).with_transform(rt.translation(-2.1, 1.05, 0.4) * rt.rotation_y(0.37) * rt.rotation_x(0.21)))
+    mirror = rt.Phong.default().with_rgb(0.1, 0.12, 0.15).with_diffuse(0.3).with_specular(0.8).with_shininess(200.0).with_reflective(0.6)
+    w.add_item(rt.build_bounding_tree(ico.into_group(mirror).with_transform(
+        rt.translation(0.45, 1.3, 1.6) * rt.rotation_z(0.5) * rt.rotation_y(1.1) * rt.scaling(1.3, 1.3, 1.3)), 4))
+    octa = rt.TriangleMesh.new()
+    top, bot = rt.point(0, 1, 0), rt.point(0, -1, 0)
+    ring = [rt.point(1, 0, 0), rt.point(0, 0, 1), rt.point(-1, 0, 0), rt.point(0, 0, -1)]
+    for i in range(4):
+        octa.add_triangle(rt.triangle(top, ring[i], ring[(i + 1) % 4]))
+        octa.add_triangle(rt.triangle(bot, ring[(i + 1) % 4], ring[i]))
+    green = rt.Phong.default().with_rgb(0.2, 0.7, 0.3).with_diffuse(0.75).with_specular(0.2)
+    w.add_item(octa.into_group(green).with_transform(rt.translation(2.6, 0.8, -0.3) * rt.rotation_y(0.6) * rt.scaling(0.8, 0.8, 0.8)))
+    blue = rt.Phong.default().with_rgb(0.25, 0.35, 0.85).with_diffuse(0.7).with_specular(0.3)
+    carved = rt.csg_difference(rt.cube().with_material(blue),
+                               octa.into_group(green).with_transform(rt.translation(0.35, 0.4, -0.6) * rt.scaling(1.1, 1.1, 1.1)))
+    w.add_item(carved.with_transform(rt.translation(-0.3, 0.55, -1.9) * rt.rotation_y(0.45) * rt.scaling(0.55, 0.55, 0.55)))
+    w.finalize_scene()
+    return w, _camera(h, v, (0.4, 2.6, -7.5), (0.1, 0.9, 0), se=1e-2, min_samples=5, deterministic=deterministic)
+
+
+EXTRA_SCENES = {"meshes": meshes, "photons": photon_room_with_map, "yard": yard, "photonbox": photon_box_with_map, "crowd": crowd}  # (bench.py --scene takes these too; not BASELINE configurations)
 
 BASELINE_SCENES = {
     "ch07": chapter07,

@@ -32,8 +32,8 @@ def photon_room(h, v, **kw):
 
 
 EXTRA = {"gallery": scenes.lights_gallery, "yard": scenes.yard, "yard-group": scenes.yard, "photons": photon_room, "photons-only": photon_room,
-         "crowd": scenes.crowd}
-for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {}), ("crowd", {}),
+         "crowd": scenes.crowd, "meshes": scenes.meshes}
+for name, kw in [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("soft", {}), ("dof", {}), ("teapot", {"lite": True}), ("dice", {"nx": 1, "ny": 1}), ("gallery", {}), ("crowd", {}), ("meshes", {}),
                  ("yard", {}), ("yard-group", {"bounded": False}), ("photons", {}), ("photons-only", {"direct": False})]:
     world, cam = (EXTRA[name] if name in EXTRA else scenes.BASELINE_SCENES[name])(32, 16, **kw)
     f = world.flatten()

@@ -301,3 +301,23 @@ def test_cpp_example_compiles_and_fails_loudly_without_a_gpu(tmp_path):
         pytest.skip("GPU present: the example is run by the gpu tests")
     r = subprocess.run([exe, str(tmp_path / "o.ppm"), "32"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU path" in r.stderr
+
+
+def test_triangle_mesh_flattens_into_a_group_of_its_faces():  # triangle.rs:164-192; include/rtmi.hpp TriangleMesh
+    verts = [rt.point(0, 0, 0), rt.point(1, 0, 0), rt.point(0, 1, 0), rt.point(0, 0, 1)]
+    mesh = rt.TriangleMesh.from_mesh(verts, [[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]])
+    assert mesh.aint_empty() and len(mesh) == 4 and not rt.TriangleMesh.new().aint_empty()
+    t = mesh.get_triangle(1)
+    assert (t.p1.x, t.p1.y, t.p1.z, t.p2.y, t.p3.z) == (0.0, 0.0, 0.0, 1.0, 1.0)
+    mesh.add_triangle(rt.triangle(verts[1], verts[2], verts[3]))
+    assert len(mesh) == 5
+    with pytest.raises(Exception):
+        mesh.add_triangle(rt.smooth_triangle(verts[0], verts[1], verts[2], rt.vector(0, 1, 0), rt.vector(0, 1, 0), rt.vector(0, 1, 0)))
+    with pytest.raises(Exception):
+        rt.TriangleMesh.from_mesh(verts, [[0, 1]])
+    mat = rt.Phong.default().with_rgb(0.2, 0.4, 0.6)
+    w = rt.World.empty()
+    w.add_item(mesh.into_group(mat).with_transform(rt.translation(1, 2, 3)))
+    w.finalize_scene()
+    f = w.flatten()
+    assert f.n_leaves == 5  # one RTMI_TRIANGLE leaf per face, all with the mesh's transform and material

@@ -75,7 +75,8 @@ def test_scheme_scenes_f32(name):
 # ("crowd": a flat world larger than every table the flat kernels stage in LDS - leaves, materials, lights and patterns from
 # global memory, scenes.crowd)
 DET = [("ch07", {}), ("ch11a", {}), ("ch11b", {}), ("teapot", {"lite": True}), ("teapot", {}), ("soft", {}), ("dof", {}),
-       ("dice", {"nx": 2, "ny": 1}), ("dice", {}), ("crowd", {})]
+       ("dice", {"nx": 2, "ny": 1}), ("dice", {}), ("crowd", {}), ("meshes", {})]
+# ("meshes": flattened TriangleMesh shapes - top level, bounded, built face by face, as a CSG operand; scenes.meshes)
 ALL_SCENES = dict(scenes.BASELINE_SCENES, **scenes.EXTRA_SCENES)
 
 
@@ -121,7 +122,7 @@ def test_subtree_of_every_item_kind(bounded, precision, deterministic):
 STO = [("ch07", {}, 160, 80), ("ch11a", {}, 160, 80), ("ch11b", {}, 160, 80), ("soft", {}, 160, 80), ("dof", {}, 160, 80),
        # the tree scenes (BoundingGroup / CSG traversal in the second-pass kernels), as shipped
        ("teapot", {"lite": True}, 160, 80), ("teapot", {}, 128, 64), ("dice", {"nx": 2, "ny": 1}, 160, 80), ("dice", {}, 128, 64),
-       ("crowd", {}, 160, 80)]
+       ("crowd", {}, 160, 80), ("meshes", {}, 160, 80)]
 
 
 @pytest.mark.parametrize("name,kw,h,v", STO, ids=[n + ("-" + "-".join("%s%s" % kv for kv in k.items()) if k else "") for n, k, _, _ in STO])
