@@ -364,7 +364,7 @@ def main():
                                  "both passes; call.* is the whole call: alone, and as the span of the timed region / calls with "
                                  "frames_in_flight calls overlapping; traffic = HBM bytes per call from PMC passes (profiles/traffic.json); "
                                  "valu_busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / GRBM_GUI_ACTIVE per XCD, lane_util = SQ_THREAD_CYCLES_VALU / (64 x "
-                                 "SQ_ACTIVE_INST_VALU), flop_per_lane_op = algorithmic FLOPs / (SQ_THREAD_CYCLES_VALU / 4) of the dominant kernel, "
+                                 "SQ_ACTIVE_INST_VALU), flop_per_lane_op = algorithmic FLOPs / SQ_THREAD_CYCLES_VALU (active lanes summed over VALU instructions) of the dominant kernel, "
                                  "from the committed PMC passes named in pmc_source (profiles/pmc_summary.json)"},
         }
         if world_size == 1 and not a.no_host_frame and not a.no_cpu_baseline:

@@ -842,8 +842,8 @@ template <typename R> __device__ __forceinline__ void open_candidate(Open<R> &op
 }
 
 // The intersections csg_root buffers, per lane: scratch memory.  (Keeping the first 4 or 8 of them in LDS, [entry][lane],
-// was measured on the dice frame: 333 ms without, 345 and 380 ms with - the per-lane scratch lines stay in the vector cache,
-// and LDS is what the pending-ray stacks need.  Nor did reading up to eight of them into registers in one batch before the
+// was measured on the dice frame twice: 333 ms without, 345 and 380 ms with (round 2), 195 / 224 / 238 ms (round 3, with LDS to
+// spare) - the per-lane scratch lines stay in the vector cache; the index arithmetic and the branch per access cost more.  Nor did reading up to eight of them into registers in one batch before the
 // filter, with every leaf's DChain packed into one word beside them, change the frame's time: 196.4 and 200.9 ms against
 // 196.0 - the filter's time is its own arithmetic and branches, not the waits for the buffer.)
 template <typename R> struct CsgBuf {

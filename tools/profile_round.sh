@@ -7,7 +7,9 @@ pre="$1"; shift
 root="${GRAFT_REPO_ROOT:-$PWD}"
 out="$root/gpurun_out/$pre"
 mkdir -p "$out"
-for spec in "ch11a shipped 6" "ch11a 1spp 12" "teapot shipped 2" "dice shipped 1" "soft shipped 2"; do
+# (PROFILE_SPECS: a subset, "scene sampling steps;..." - a call of gpurun holds about half of the twelve)
+IFS=";" read -ra SPECS <<< "${PROFILE_SPECS:-ch07 shipped 4;ch07 1spp 12;ch11a shipped 6;ch11a 1spp 12;ch11b shipped 6;ch11b 1spp 12;teapot shipped 3;teapot 1spp 12;soft shipped 2;dof shipped 1;dice shipped 1;dice 1spp 6}"
+for spec in "${SPECS[@]}"; do
   set -- $spec
   scene=$1; samp=$2; steps=$3
   args="--scene $scene --sampling $samp --steps $steps --warmup 1 --frames-in-flight 1"

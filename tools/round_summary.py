@@ -17,7 +17,7 @@ order = ["ch07_1spp", "ch07_shipped", "ch11a_1spp", "ch11a_shipped", "ch11b_1spp
 out = {"_what": "every BASELINE configuration at 3840x2160, f32, one MI355X, bench.py --frames-in-flight 2 (tools/scenes_bench.sh), build %s; frac = the dominant "
                 "kernel alone (roofline.frac), frac_call_alone = the whole call alone" % pre,
        "rows": {k: rows[k] for k in order if k in rows}}
-json.dump(out, open(os.path.join(root, "profiles", "r02_all_scenes.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", pre[:3] + "_all_scenes.json"), "w"), indent=1)
 traffic = {"_what": "HBM bytes per rtmi_render_device call (all its launches), rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (profiles/%s_*_pmc.txt, "
                     "tools/pmc.sh), KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; 3840x2160 f32, build %s" % (pre, pre)}
 src = os.path.join(root, "gpurun_out", pre)
