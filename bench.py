@@ -12,7 +12,7 @@ with --gpus N > 1 it starts torch.distributed.run itself as a child BEFORE anyth
 child's output and exit code on (the reference's fan-out needs no launcher either: camera.rs:260-264).
 N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
 gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default: 2
-on one GPU, 3 from 2 GPUs on, where a rank's share is short: tools/inflight.py, profiles/r02d_rank_share.txt) frames are
+on one GPU, 3 from 2 GPUs on, where a rank's share is short: tools/inflight.py, profiles/r03b_rank_share.txt) frames are
 in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside the library): the
 ends of one frame's kernels - a few waves finishing the deepest pixels - and its gather overlap the next frame's first
 pass.  Every frame is rendered completely and gathered inside the timed region; F = 1 runs the frames strictly one after
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames rendered concurrently, one HIP stream each (the library has 4 work-queue slots per device); 0 = 2 on one GPU, 3 with 2 GPUs or more "
-                         "(measured shares of the headline frame, ms per frame with 2 / 3 in flight: 1/2 of it 13.3 / 12.7, 1/4 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
+                         "(round 2's shares of the headline frame, ms per frame with 2 / 3 in flight: 1/2 of it 13.3 / 12.7, 1/4 7.56 / 6.68, 1/8 4.61 / 4.37; the whole frame 26.0 / 27.3)")
     ap.add_argument("--scene", default="ch11a", help="ch07 | ch11a | ch11b | teapot | soft | dof | dice (BASELINE configurations) | photons | yard | photonbox")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
