@@ -130,7 +130,7 @@ def test_adaptive_frame_rows_against_the_oracle(precision):
     """The headline workload itself - chapter-11a, 3840x2160, adaptive as shipped - against the oracle on 136 of its rows:
     17 row tiles (8 rows each, spread over the frame) rendered as rank shares, which gives the device's sample count for
     exactly those rows (a share's pixels are the frame's, bit for bit: the test above), and the oracle on the same rows
-    with the same seed.  Bars: f64 PSNR >= 60 dB and sample counts within 2e-4; f32 PSNR >= 35 dB, counts within 5 %."""
+    with the same seed.  Bars: f64 PSNR >= 60 dB and sample counts within 2e-4; f32 PSNR >= 35 dB, counts within 1e-3 (measured: 6e-6)."""
     import torch
     world, cam = scenes.chapter11a(H, V)
     n_tiles = V // 8
@@ -160,7 +160,7 @@ def test_adaptive_frame_rows_against_the_oracle(precision):
     rel = abs(samples - ref_samples) / ref_samples
     print("adaptive rows: PSNR %.1f dB, samples %d oracle %d (rel %.2e)" % (p, samples, ref_samples, rel))
     assert p >= (60.0 if precision == 1 else 35.0), p
-    assert rel <= (2e-4 if precision == 1 else 5e-2), rel
+    assert rel <= (2e-4 if precision == 1 else 1e-3), rel
 
 
 def test_rgb8_conversion_of_the_whole_frame():
