@@ -1381,6 +1381,14 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
                 run = (cleaf[i].gskip != 0u || run >= (uint32_t)CSG_RUN) ? 1u : run + 1u;
                 cleaf[i].run = run;
             }
+            // one operator over two leaves of at most two roots each: csg_pair (f32 kernels)
+            if (sizeof(R) == 4 && nd.leaf_count == 2 && nd.csg_count == 1) {
+                const uint32_t k0 = leaves[nd.leaf_first].kind & LEAF_KIND_MASK, k1 = leaves[nd.leaf_first + 1].kind & LEAF_KIND_MASK;
+                const uint32_t c = L.leaf_csg[nd.leaf_first];
+                const bool two = (k0 == RTMI_SPHERE || k0 == RTMI_CUBE) && (k1 == RTMI_SPHERE || k1 == RTMI_CUBE);
+                if (two && c != NONE && c == L.leaf_csg[nd.leaf_first + 1] && L.csgs[c].left_end == nd.leaf_first + 1)
+                    cleaf[nd.leaf_first].run |= L.csgs[c].op << CSG_PAIR_SHIFT;
+            }
         }
     }
     int rc;

@@ -170,6 +170,9 @@ struct alignas(32) DCsgLeaf {
     uint32_t run;
 };
 constexpr int CSG_RUN = 32; // (a bit per leaf in a 32-bit word)
+// DCsgLeaf::run of a root's FIRST leaf also says (f32 scenes) that the root is ONE operator over two leaves of at most two
+// roots each - spheres, cubes - and which operator (csg_pair): the lens of chapter-16, most CSG of the book's scenes
+constexpr uint32_t CSG_RUN_MASK = 0xFFu, CSG_PAIR_SHIFT = 8; // run | (RTMI_NODE_CSG_* of a pair root) << 8, 0 = not a pair root
 // A leaf's CSG ancestors as two masks over the root's operator flags (bit 2b = inl, 2b + 1 = inr of operator b): the flags
 // CsgOp::eval (csg.rs:26-32) needs clear / set for a root of this leaf to pass (see csg_root).
 struct alignas(16) DChain { unsigned long long zero, one; };
@@ -855,12 +858,63 @@ template <typename R> struct CsgBuf {
     __device__ __forceinline__ void set_id(int i, uint32_t id) { deep_id[i] = id; }
 };
 
+// A CSG root that is one operator over two leaves of at most two roots each (CsgPair::intersect + filter_intersections,
+// csg.rs:97-124, for that case), f32 path: no buffer, no sort, no loop - the four roots stay in registers and each passes
+// or not by where it lies in the OTHER leaf's interval, which is what the filter's inl / inr flags say at its turn.  Ties go
+// as the reference's stable sort of left ++ right has them: a left root at a right root's parameter comes first (it sees
+// inr as it was before that right root toggled it), a right root at a left root's parameter comes after it.
+// Returns false for a lane whose leaf gave another number of roots than 0 or 2 (never, for spheres and cubes): that lane
+// takes the general path.
+template <int MODE>
+__device__ __forceinline__ bool csg_pair(const DScene<float> &sc, uint32_t op, uint32_t la, const Ray<float> &ray, uint32_t origin_leaf, uint32_t origin_side,
+                                         Hit<float> &best, float t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<float> &open, Stats &st) {
+    const uint32_t lb = la + 1u;
+    const DLeaf<float> &ga = sc.leaves[la], &gb = sc.leaves[lb];
+    const uint32_t ka = ga.kind, kb = gb.kind;
+    float a[4], b[4], u, v;
+    int na = 0, nb = 0;
+    if (!(MODE == MODE_ANY && !(ka & LEAF_CAST_SHADOW))) na = leaf_roots(ga, ka, sc.tris, ray, la == origin_leaf, origin_side, a, u, v, st);
+    // (the guard record of the general path: without a root on its left side an Intersection or Difference is empty)
+    const bool need_b = !(MODE == MODE_ANY && !(kb & LEAF_CAST_SHADOW)) && (op == (uint32_t)RTMI_NODE_CSG_UNION || na > 0);
+    if (need_b) nb = leaf_roots(gb, kb, sc.tris, ray, lb == origin_leaf, origin_side, b, u, v, st);
+    if ((na != 0 && na != 2) || (nb != 0 && nb != 2)) return false;
+    const bool ha = na == 2, hb = nb == 2;
+    // inside the other leaf at a root's turn
+    auto in_b = [&](float x) { return hb && b[0] < x && x <= b[1]; };
+    auto in_a = [&](float y) { return ha && a[0] <= y && y < a[1]; };
+    bool ka0, ka1, kb0, kb1; // does the root pass (CsgOp::eval, csg.rs:26-32)
+    if (op == (uint32_t)RTMI_NODE_CSG_UNION) { ka0 = !in_b(a[0]); ka1 = !in_b(a[1]); kb0 = !in_a(b[0]); kb1 = !in_a(b[1]); }
+    else if (op == (uint32_t)RTMI_NODE_CSG_INTERSECTION) { ka0 = in_b(a[0]); ka1 = in_b(a[1]); kb0 = in_a(b[0]); kb1 = in_a(b[1]); }
+    else { ka0 = !in_b(a[0]); ka1 = !in_b(a[1]); kb0 = in_a(b[0]); kb1 = in_a(b[1]); }
+    ka0 = ka0 && ha; ka1 = ka1 && ha; kb0 = kb0 && hb; kb1 = kb1 && hb;
+    if (MODE == MODE_COLLECT) {
+        // survivors in front of the hit, per leaf: odd count = still open, entered at its last such root
+        const bool fa0 = ka0 && ((la == hit_leaf) ? (0u < hit_ord) : (a[0] < t_limit)), fa1 = ka1 && ((la == hit_leaf) ? (1u < hit_ord) : (a[1] < t_limit));
+        const bool fb0 = kb0 && ((lb == hit_leaf) ? (0u < hit_ord) : (b[0] < t_limit)), fb1 = kb1 && ((lb == hit_leaf) ? (1u < hit_ord) : (b[1] < t_limit));
+        const uint32_t ca = (fa0 ? 1u : 0u) + (fa1 ? 1u : 0u), cb = (fb0 ? 1u : 0u) + (fb1 ? 1u : 0u);
+        if (ca) { if (la == hit_leaf) open.hit_parity = ca; if (ca & 1u) open_candidate(open, la, hit_leaf, fa1 ? a[1] : a[0]); }
+        if (cb) { if (lb == hit_leaf) open.hit_parity = cb; if (cb & 1u) open_candidate(open, lb, hit_leaf, fb1 ? b[1] : b[0]); }
+        return true;
+    }
+    // the first survivor with t >= 0 in ascending order (ties: the left leaf's root first, the lower ordinal first)
+    float bt = Lim<float>::inf();
+    uint32_t bl = NONE, bo = 0u;
+    auto take = [&](bool keep, float t, uint32_t leaf, uint32_t ord) { if (keep && t >= 0.0f && t < bt) { bt = t; bl = leaf; bo = ord; } };
+    take(ka0, a[0], la, 0u); take(ka1, a[1], la, 1u); take(kb0, b[0], lb, 0u); take(kb1, b[1], lb, 1u);
+    if (bl != NONE && bt < t_limit && bt < best.t) { best.t = bt; best.leaf = bl; best.ord = bo; }
+    return true;
+}
+
 // Evaluate one CSG root (CsgPair::intersect + filter_intersections, csg.rs:97-124, recursively):
 // buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
 // its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
 template <typename R, int MODE>
 __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
                          Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+    if constexpr (sizeof(R) == 4) {
+        const uint32_t pair_op = sc.csg_leaf[leaf_first].run >> CSG_PAIR_SHIFT; // (wave-uniform)
+        if (pair_op != 0u && csg_pair<MODE>(sc, pair_op, leaf_first, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st)) return;
+    }
     CsgBuf<R> buf;
     int k = 0, first_i = -1; // (first_*: the smallest root so far, the earliest of equals)
     R first_t = (R)0;
@@ -873,7 +927,7 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
     // goes through the full test of only those leaves that some lane of the wave still needs.  (A ray through a die of
     // chapter-16 passes the spheres of two or three of its 21 dimples.)
     for (uint32_t base = leaf_first; base < leaf_end;) {
-        uint32_t run = sc.csg_leaf[base].run;
+        uint32_t run = sc.csg_leaf[base].run & CSG_RUN_MASK;
         run = min(run == 0u ? 1u : run, min((uint32_t)CSG_RUN, leaf_end - base));
         uint32_t near = 0u, visit = 0u; // per lane: leaves to test in full; wave: leaves some lane tests in full
         CYC5_BEGIN(c_p1);
