@@ -561,6 +561,16 @@ struct Layout {
         inner(0, root, kids, sh);
         if (err_code != RTMI_OK) return false;
         if (stack_need(0) > NODE_STACK) return bad(RTMI_ERR_UNSUPPORTED, "scene tree needs a deeper traversal stack than " + std::to_string(NODE_STACK));
+        // CSG roots that are ONE operator over two leaves of at most two roots each - spheres, cubes: the operator goes into
+        // the node's flags (csg_pair of the f32 kernels; the f64 kernels ignore it)
+        for (DNode &nd : nodes) {
+            if (!(nd.flags & NODE_CSGROOT) || nd.leaf_count != 2 || nd.csg_count != 1) continue;
+            const int k0 = d->leaves[leaf_orig[nd.leaf_first]].kind, k1 = d->leaves[leaf_orig[nd.leaf_first + 1]].kind;
+            const uint32_t c = leaf_csg[nd.leaf_first];
+            const bool two = (k0 == RTMI_SPHERE || k0 == RTMI_CUBE) && (k1 == RTMI_SPHERE || k1 == RTMI_CUBE);
+            if (two && c != NONE && c == leaf_csg[nd.leaf_first + 1] && csgs[c].left_end == nd.leaf_first + 1)
+                nd.flags |= csgs[c].op << NODE_PAIR_SHIFT;
+        }
         return true;
     }
 };
@@ -1380,14 +1390,6 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
             for (uint32_t i = nd.leaf_first + nd.leaf_count; i-- > nd.leaf_first;) {
                 run = (cleaf[i].gskip != 0u || run >= (uint32_t)CSG_RUN) ? 1u : run + 1u;
                 cleaf[i].run = run;
-            }
-            // one operator over two leaves of at most two roots each: csg_pair (f32 kernels)
-            if (sizeof(R) == 4 && nd.leaf_count == 2 && nd.csg_count == 1) {
-                const uint32_t k0 = leaves[nd.leaf_first].kind & LEAF_KIND_MASK, k1 = leaves[nd.leaf_first + 1].kind & LEAF_KIND_MASK;
-                const uint32_t c = L.leaf_csg[nd.leaf_first];
-                const bool two = (k0 == RTMI_SPHERE || k0 == RTMI_CUBE) && (k1 == RTMI_SPHERE || k1 == RTMI_CUBE);
-                if (two && c != NONE && c == L.leaf_csg[nd.leaf_first + 1] && L.csgs[c].left_end == nd.leaf_first + 1)
-                    cleaf[nd.leaf_first].run |= L.csgs[c].op << CSG_PAIR_SHIFT;
             }
         }
     }

@@ -60,6 +60,8 @@ constexpr uint32_t NODE_CAST_SHADOW = 1u << 2; // some leaf below casts shadows
 constexpr uint32_t NODE_AXIS_SHIFT = 4;         // bits 4-5: 1 + the axis along which the node's two children are sorted by centre (0: no order)
 constexpr uint32_t NODE_TRIBVH = 1u << 6;      // f32 path: everything below this node (Groups / BoundingGroups of triangles, other primitives and CSG roots,
                                                // all with finite bounds) has been rebuilt as a BVH of its own (DBvh2): csg_count = the entry of its root
+constexpr uint32_t NODE_PAIR_SHIFT = 8, NODE_PAIR_MASK = 7u;  // bits 8-10 of a CSG root: RTMI_NODE_CSG_* of its one operator if the root is that operator
+                                                              // over two leaves of at most two roots each (spheres, cubes: csg_pair), else 0
 constexpr uint32_t NODE_ALLTRI = 1u << 3;      // not a CSG root, every direct leaf is a triangle: wtris[csg_count + i] is leaf
                                                // leaf_first + i in world space (f32 path)
 
@@ -170,9 +172,6 @@ struct alignas(32) DCsgLeaf {
     uint32_t run;
 };
 constexpr int CSG_RUN = 32; // (a bit per leaf in a 32-bit word)
-// DCsgLeaf::run of a root's FIRST leaf also says (f32 scenes) that the root is ONE operator over two leaves of at most two
-// roots each - spheres, cubes - and which operator (csg_pair): the lens of chapter-16, most CSG of the book's scenes
-constexpr uint32_t CSG_RUN_MASK = 0xFFu, CSG_PAIR_SHIFT = 8; // run | (RTMI_NODE_CSG_* of a pair root) << 8, 0 = not a pair root
 // A leaf's CSG ancestors as two masks over the root's operator flags (bit 2b = inl, 2b + 1 = inr of operator b): the flags
 // CsgOp::eval (csg.rs:26-32) needs clear / set for a root of this leaf to pass (see csg_root).
 struct alignas(16) DChain { unsigned long long zero, one; };
@@ -909,10 +908,10 @@ __device__ __forceinline__ bool csg_pair(const DScene<float> &sc, uint32_t op, u
 // buffer every root of every leaf below, visit them in ascending t, and let each pass the filters of
 // its CSG ancestors bottom-up.  MODE_CLOSEST / MODE_ANY stop at the first survivor with t >= 0.
 template <typename R, int MODE>
-__device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf, uint32_t origin_side,
-                         Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
+__device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t node_flags, uint32_t leaf_first, uint32_t leaf_count, const Ray<R> &ray, uint32_t origin_leaf,
+                         uint32_t origin_side, Hit<R> &best, R t_limit, uint32_t hit_leaf, uint32_t hit_ord, Open<R> &open, Stats &st) {
     if constexpr (sizeof(R) == 4) {
-        const uint32_t pair_op = sc.csg_leaf[leaf_first].run >> CSG_PAIR_SHIFT; // (wave-uniform)
+        const uint32_t pair_op = (node_flags >> NODE_PAIR_SHIFT) & NODE_PAIR_MASK; // (wave-uniform)
         if (pair_op != 0u && csg_pair<MODE>(sc, pair_op, leaf_first, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st)) return;
     }
     CsgBuf<R> buf;
@@ -927,7 +926,7 @@ __device__ __forceinline__ void csg_root(const DScene<R> &sc, uint32_t leaf_firs
     // goes through the full test of only those leaves that some lane of the wave still needs.  (A ray through a die of
     // chapter-16 passes the spheres of two or three of its 21 dimples.)
     for (uint32_t base = leaf_first; base < leaf_end;) {
-        uint32_t run = sc.csg_leaf[base].run & CSG_RUN_MASK;
+        uint32_t run = sc.csg_leaf[base].run;
         run = min(run == 0u ? 1u : run, min((uint32_t)CSG_RUN, leaf_end - base));
         uint32_t near = 0u, visit = 0u; // per lane: leaves to test in full; wave: leaves some lane tests in full
         CYC5_BEGIN(c_p1);
@@ -1405,7 +1404,7 @@ __device__ __forceinline__ void packet_tris(const DScene<float> &sc, uint32_t ro
             if (!(nd.flags & NODE_CSGROOT) || leaf_first + leaf_count > sc.n_leaves) { st.flag(RTMI_STAT_OVERFLOW); return; } // (never)
             if (in && !(MODE == MODE_ANY && best.leaf != NONE)) {
                 st.inc(RTMI_STAT_NODE_VISITS);
-                csg_root<float, MODE>(sc, leaf_first, leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+                csg_root<float, MODE>(sc, nd.flags, leaf_first, leaf_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
             }
             if (MODE == MODE_ANY && __ballot(mine && best.leaf == NONE) == 0ull) { leave(); return; }
             pop = true;
@@ -1493,6 +1492,9 @@ __device__ __forceinline__ void packet_scene(const DScene<float> &sc, const Ray<
         if (hm == 0ull) continue;
         if (h) st.inc(RTMI_STAT_NODE_VISITS);
         if (flags & (NODE_TRIBVH | NODE_CSGROOT)) { // the node's own BVH, or the CSG root itself as a one-entry tree (its NODE_VISITS is counted there)
+            // (csg_root has ONE call site in this walk, inside packet_tris: a second one here - the root evaluated at once, without
+            // the trip through the entry loop - made every tree kernel slower, teapot 23.4 -> 27.7 ms with no CSG in it: three
+            // more inlined copies of it cost registers everywhere)
             if (h && (flags & NODE_CSGROOT)) st.add(RTMI_STAT_NODE_VISITS, 0xFFFFFFFFu);
             const uint32_t entry = (flags & NODE_TRIBVH) ? nd.csg_count : top;
             if (sc.has_units) packet_tris<MODE, true>(sc, entry, h, sp, ray, rs, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
@@ -1615,7 +1617,7 @@ __device__ __forceinline__ void traverse_body(const DScene<R> &sc, const Ray<R> 
         }
         if (!have) break;
         if (w_flags & NODE_CSGROOT) {
-            csg_root<R, MODE>(sc, w_first, w_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
+            csg_root<R, MODE>(sc, w_flags, w_first, w_count, ray, origin_leaf, origin_side, best, t_limit, hit_leaf, hit_ord, open, st);
         } else {
             bool done = false;
             if constexpr (sizeof(R) == 4) {
