@@ -12,7 +12,7 @@ with --gpus N > 1 it starts torch.distributed.run itself as a child BEFORE anyth
 child's output and exit code on (the reference's fan-out needs no launcher either: camera.rs:260-264).
 N > 1 shards the frame by 8-row tiles, round-robin over the ranks (strong scaling: the frame is fixed), and
 gathers the rows to rank 0 with RCCL inside the timed region (raytracing_amd/tiles.py).  --frames-in-flight F (default: 2
-on one GPU, 3 from 2 GPUs on, where a rank's share is short: tools/inflight.py, profiles/r03b_rank_share.txt) frames are
+on one GPU, 3 from 2 GPUs on, where a rank's share is short: tools/inflight.py, profiles/r03c_rank_share.txt) frames are
 in flight at once, each on its own HIP stream with its own buffer (and its own work-queue slot inside the library): the
 ends of one frame's kernels - a few waves finishing the deepest pixels - and its gather overlap the next frame's first
 pass.  Every frame is rendered completely and gathered inside the timed region; F = 1 runs the frames strictly one after
