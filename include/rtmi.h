@@ -238,7 +238,12 @@ void rtmi_scene_destroy(rtmi_scene *scene);
 
 /* Replaces `Camera::render(&self, &World) -> Canvas` (camera.rs:155-161).  rgb_out is a HOST
  * buffer of hsize*vsize*3 floats, row-major, un-clipped linear colour like Canvas::data
- * (canvas.rs:8-21).  Renders the whole frame on the current device (opts->rank/nranks ignored). */
+ * (canvas.rs:8-21).  Renders the whole frame on the current device (opts->rank/nranks ignored).
+ * The frame is rendered into a device buffer kept with the scene and leaves through pinned staging
+ * in 8 pieces, each copied into rgb_out by host threads while the next arrives (RTMI_HOST_COPY_THREADS
+ * in the environment, default 4, at most 8); the buffers are created by a scene's first call
+ * and freed with it.  Concurrent calls on ONE scene are allowed: the second caller uses buffers of
+ * its own for that call.                                                                          */
 int rtmi_render(const rtmi_scene *scene, const rtmi_camera *camera, const rtmi_render_opts *opts,
                 float *rgb_out, rtmi_stats *stats_out);
 
