@@ -1704,7 +1704,7 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
     rp.keep_lanes = inlane ? (uint32_t)std::max(1l, std::min(64l, env_keep)) : 65u;
     rp.inlane_need = (uint32_t)std::max(0l, env_need);
     rp.inlane_max = inlane ? (uint32_t)std::max(0l, env_max) : 0u;
-    rp.pad = 0;
+    rp.heap_slots = 0; // (launch_render_kernel sets it where the call has a heap workspace)
     void *work = nullptr;
     int slot = -1;
     std::unique_lock<std::mutex> lock(g_pool_mutex, std::defer_lock);
@@ -1718,7 +1718,10 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
                                                   std::to_string(RTMI_STATIC_SCRATCH_MB) + " MiB) holds " + std::to_string(cap) + " in " + (f64 ? "f64" : "f32") +
                                                   " mode; render in row-tile shares (opts.rank / nranks) or use rtmi_render_device");
     }
-    if (open_ended) {
+    // (a photon scene's f32 kernels keep their candidate heaps in the tail of the call's work memory - photon_estimate - so such
+    // a call takes a slot of the pool even when it has no second pass)
+    const bool heap_work = !f64 && s->n_photons != 0 && !static_work;
+    if (open_ended || heap_work) {
         lock.lock(); // held until both kernels are enqueued: calls sharing a stream must not interleave their launches
         if (static_work) { work = static_work; wbytes = static_bytes; }
         else {
@@ -1726,9 +1729,11 @@ static int launch_render(const rtmi_scene *s, const rtmi_camera *c, const rtmi_r
             if (rc != RTMI_OK) return rc;
             work = g_pool[s->device].buf[slot];
         }
-        HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st)); // (the array keeps the last call's contents: the counters must start at zero)
+        if (open_ended) HIP_TRY(hipMemsetAsync(work, 0, WORK_HEADER_BYTES, st)); // (the array keeps the last call's contents: the counters must start at zero)
     }
-    const int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
+    if (s->n_photons != 0) grid = std::min(grid, (int)HEAP_WS_SLOTS); // (a wave's run in the heap workspace is its block's: photon_estimate)
+    int grid2 = open_ended ? s->num_cu * 4 * RTMI_RESAMPLE_WAVES : 0;
+    if (s->n_photons != 0) grid2 = std::min(grid2, (int)HEAP_WS_SLOTS);
     if (f64) launch_render_kernel<double>(tree, grid, grid2, st, s->h64, cam, rp, d_out, ds, work, wbytes, between, state);
     else launch_render_kernel<float>(tree, grid, grid2, st, s->h32, cam, rp, d_out, ds, work, wbytes, between, state);
     HIP_TRY(hipGetLastError());

@@ -315,7 +315,7 @@ struct DRender {
     int32_t tiles_x, local_tile_rows8; // 8-row tile rows owned by this rank
     int32_t n_tiles;
     uint32_t first, group, ppw, n_visits; // first pass (render_kernel): samples before a pixel's fate is decided, lanes per pixel, pixels per wave visit = 64 / group, visits
-    uint32_t keep_lanes, inlane_need, inlane_max, pad; // first pass: a lane keeps its pixel past `first` samples while at least keep_lanes lanes of its wave do, the
+    uint32_t keep_lanes, inlane_need, inlane_max, heap_slots; // (heap_slots: runs in the photon heap workspace, 0 = none) first pass: a lane keeps its pixel past `first` samples while at least keep_lanes lanes of its wave do, the
                                                         // pixel is predicted to need at most inlane_need more, and it has taken fewer than first + inlane_max
 };
 
@@ -1963,8 +1963,15 @@ constexpr int HEAP_ARITY = RTMI_HEAP_ARITY;
 #define RTMI_HEAP_LDS 21
 #endif
 constexpr int HEAP_LDS = RTMI_HEAP_LDS; // entries of the heap held in LDS (21: the top three levels at arity 4; measured 5 / 21 / 37 / 53 / 85: 356 / 256 / 317 / 394 / 425 ms on the 4K photon frame, 382 with none - more LDS per wave costs waves per CU)
+// The candidates beyond the LDS-resident top of the heap.  Per-lane scratch interleaves the lanes dword by dword, so a heap
+// walk - every lane at a different index - touches one 64-byte sector per lane and dword for four bytes of use (the 270 GB a
+// 1080p frame moved).  The render kernels therefore get a workspace in the call's work memory, LANE-major: a lane's
+// entries are one contiguous run of 8-byte pairs, the four children of a heap entry share a 64-byte line (heap_ws: the
+// lane's own run, or null - the probe kernels, the f64 mode, work memory too small - for the scratch array).
+constexpr int HEAP_WS_ENTRIES = RTMI_MAX_NEAREST - HEAP_LDS; // pairs per lane
+constexpr uint32_t HEAP_WS_SLOTS = 4096;                     // waves per launch that can have a run each (the host caps the grids of photon kernels at this)
 template <typename R>
-__device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V3<R> normalv, V3<R> surface_color, Stats &st) {
+__device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V3<R> normalv, V3<R> surface_color, Stats &st, HeapEntry<R> *heap_ws = nullptr) {
     const uint32_t n = sc.n_photons;
     const int k = (int)min(sc.n_nearest, (uint32_t)RTMI_MAX_NEAREST);
     HeapEntry<R> he[RTMI_MAX_NEAREST];
@@ -1973,9 +1980,10 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
     // the memory system from per-lane scratch (PMC: 515 GB moved per 1920x1080 frame, 12 x the photons read, before).  (One wave per workgroup: the lane is threadIdx.x & 63.)
     __shared__ HeapEntry<R> heap_top[HEAP_LDS][64];
     const int heap_lane = (int)(threadIdx.x & 63u);
-    auto heap_ld = [&](int i) -> HeapEntry<R> { return i < HEAP_LDS ? heap_top[i][heap_lane] : he[i]; };
+    auto heap_ld = [&](int i) -> HeapEntry<R> { return i < HEAP_LDS ? heap_top[i][heap_lane] : (heap_ws ? heap_ws[i - HEAP_LDS] : he[i]); };
     auto heap_st = [&](int i, const HeapEntry<R> &e) {
         if (i < HEAP_LDS) heap_top[i][heap_lane] = e;
+        else if (heap_ws) heap_ws[i - HEAP_LDS] = e; // (wave-uniform choice)
         else he[i] = e;
     };
     int cnt = 0;
@@ -2078,7 +2086,8 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
 // above it ("weight") and adds weight * (clipped direct light + emissive) to the sample.
 // PHOTON: the scene may carry a photon map (kernels of their own: the search's per-lane arrays are not for the others to pay)
 template <typename R, int TREE, bool PHOTON = false>
-__device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps) {
+__device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int remaining, Rng &rng, Stats &st, Hit<R> *first_hit, Comps<R> *first_comps,
+                                          HeapEntry<R> *heap_ws = nullptr) {
     const R EPS = (R)RTMI_EPSILON;
     V3<R> acc = mk<R>(0, 0, 0);
     R weight = (R)1;
@@ -2127,7 +2136,7 @@ __device__ __forceinline__ V3<R> color_at(const DScene<R> &sc, Ray<R> ray, int r
             CYC3_END(st, 1, c_prep);
             V3<R> surface = mk<R>(0, 0, 0);
             if constexpr (PHOTON) {
-                if (sc.n_photons) surface = photon_estimate(sc, c.point, c.normalv, surface_color, st); // materials.rs:376-384
+                if (sc.n_photons) surface = photon_estimate(sc, c.point, c.normalv, surface_color, st, heap_ws); // materials.rs:376-384
             }
             const uint32_t n_direct = (PHOTON && sc.no_direct) ? 0u : sc.n_lights; // world.direct_illumination_enabled(), materials.rs:386
             for (uint32_t li = 0; li < n_direct; ++li) { // materials.rs:386-397

@@ -129,16 +129,23 @@ __device__ __forceinline__ void stats_add(Stats &a, const Stats &b) {
 #endif
 }
 
+// This wave's run in the photon heap workspace (photon_estimate), or null.
+template <typename R, bool PHOTON> __device__ __forceinline__ HeapEntry<R> *heap_run(HeapEntry<R> *ws, const DRender &rp) {
+    if constexpr (!PHOTON) return nullptr;
+    if (!ws || blockIdx.x >= rp.heap_slots) return nullptr; // (wave-uniform; the host caps the grid, so the second test never fails)
+    return ws + ((size_t)blockIdx.x * 64u + (threadIdx.x & 63u)) * (size_t)HEAP_WS_ENTRIES;
+}
+
 // One sample of Camera::multisample's loop body (camera.rs:274-276,283-285,292-296): sample 0 is the centred ray.
 template <typename R, int TREE, bool PHOTON = false>
-__device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<double> &cam, Rng &rng, Stats &st, int px, int py, uint32_t s) {
+__device__ __forceinline__ V3<R> take_sample(const DScene<R> &sc, const DCamera<double> &cam, Rng &rng, Stats &st, int px, int py, uint32_t s, HeapEntry<R> *heap_ws = nullptr) {
     rng_begin(rng, (uint32_t)(py * cam.hsize + px), s);
     st.inc(RTMI_STAT_SAMPLES);
     st.fl += camera_flops(cam);
     CYC3_BEGIN(c_cam);
     Ray<R> ray = camera_ray<R>(cam, px, py, s != 0, rng);
     CYC3_END(st, 0, c_cam);
-    const V3<R> c = color_at<R, TREE, PHOTON>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr);
+    const V3<R> c = color_at<R, TREE, PHOTON>(sc, ray, (int)sc.max_depth, rng, st, nullptr, nullptr, heap_ws);
     stats_sample_end(st);
     return c;
 }
@@ -244,10 +251,11 @@ template <typename R, int TREE, bool SPREAD, bool PHOTON = false, bool DRAW = fa
 __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_TREE ? RTMI_WAVES_TREE : RTMI_WAVES) render_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, float *__restrict__ out,
                                                     unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                     DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
-                                                    uint32_t wk_cap, DPixelState<R> *__restrict__ state) {
+                                                    uint32_t wk_cap, DPixelState<R> *__restrict__ state, HeapEntry<R> *__restrict__ heap_ws) {
     // (the work pointers are separate __restrict__ arguments so that the compiler can prove the scene records are never
     // written in this kernel and fetch the wave-uniform ones with scalar loads)
     stage_scene<R, TREE>(sc);
+    HeapEntry<R> *const heap = heap_run<R, PHOTON>(heap_ws, rp);
     const int lane = threadIdx.x & 63;
     Stats st;
     stats_begin<R, TREE, PHOTON>(st, lane);
@@ -298,7 +306,7 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_
         bool go = SPREAD ? true : (valid && need_more(cam, sum, sos, (R)cnt, cnt)), queued = false, full = false, grouped = SPREAD; // (SPREAD: every lane comes along for the shuffles)
         while (go) { // wave-uniform until the pixels' sums hold `first` samples
             V3<R> c = mk<R>(0, 0, 0);
-            if (!SPREAD || valid) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, st, x, y, grouped ? sidx : cnt);
+            if (!SPREAD || valid) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, st, x, y, grouped ? sidx : cnt, heap);
             CYC4_BEGIN(c_book);
             // camera.rs:277-278: BOTH sums start from the first sample itself - the sum of squares from c, not from c * c -
             // and only the later samples enter it squared (camera.rs:286,297)
@@ -573,12 +581,13 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_
                                                       unsigned long long *__restrict__ stats, uint32_t *__restrict__ wk_hdr,
                                                       const DWorkItem<R> *__restrict__ wk_light, DWorkItem<R> *__restrict__ wk_heavy,
                                                       uint32_t *__restrict__ wk_final, uint32_t *__restrict__ wk_unit_pixel, uint32_t wk_cap,
-                                                      uint32_t wk_unit_cap, int pass, DPixelState<R> *__restrict__ state) {
+                                                      uint32_t wk_unit_cap, int pass, DPixelState<R> *__restrict__ state, HeapEntry<R> *__restrict__ heap_ws) {
     Stats st;
     stats_zero(st);
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
     const int lane = threadIdx.x & 63;
+    HeapEntry<R> *const heap = heap_run<R, PHOTON>(heap_ws, rp);
     const uint32_t n_heavy = min(wk_hdr[WK_HEAVY_COUNT], wk_cap); // (fixed by render_kernel)
     const uint32_t n_light = pass == 0 ? min(wk_hdr[WK_LIGHT_COUNT], wk_cap) : 0u;
     // the heavy pixels of the sequential loop: the first pass's in pass 0, the leftovers in the last launch
@@ -671,7 +680,7 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
             stats_begin<R, TREE, PHOTON>(ls, lane);
-            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, ox, oy, s);
+            if (has && !(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, ox, oy, s, heap);
             // the pixel's sums after each of the group's samples, added up one after the other like the reference's loop
             V3<R> sj, qj;
             seq_scan(sum0, sos0, c, G, j, sj, qj);
@@ -706,8 +715,9 @@ constexpr int UNIT_BATCH_MAX = 16;
 template <typename R, int TREE, bool PHOTON = false>
 __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_TREE ? RTMI_WAVES_TREE : RTMI_WAVES) units_kernel(DScene<R> sc, DCamera<double> cam, DRender rp, uint32_t *__restrict__ wk_hdr,
                                                    const DWorkItem<R> *__restrict__ wk_heavy, const uint32_t *__restrict__ wk_unit_pixel,
-                                                   DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass) {
+                                                   DChunk<R> *__restrict__ wk_chunks, uint32_t wk_cap, uint32_t wk_unit_cap, int pass, HeapEntry<R> *__restrict__ heap_ws) {
     stage_scene<R, TREE>(sc);
+    HeapEntry<R> *const heap = heap_run<R, PHOTON>(heap_ws, rp);
     Rng rng;
     rng.k0 = rp.seed_lo; rng.k1 = rp.seed_hi;
     const int lane = threadIdx.x & 63;
@@ -738,7 +748,7 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_
             V3<R> c = mk<R>(0, 0, 0);
             Stats ls;
             stats_begin<R, TREE, PHOTON>(ls, lane);
-            if (!(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, px, py, s);
+            if (!(cam.max_samples > 0 && s >= (uint32_t)cam.max_samples)) c = take_sample<R, TREE, PHOTON>(sc, cam, rng, ls, px, py, s, heap);
             DChunk<R> *ch = wk_chunks + (u0 + i);
             ch->col[0][lane] = c.x; ch->col[1][lane] = c.y; ch->col[2][lane] = c.z;
             ch->st[0][lane] = (ls.get(RTMI_STAT_PRIMARY) & 0xFFu) | ((ls.get(RTMI_STAT_SAMPLES) & 0xFFu) << 8) | (min(ls.get(RTMI_STAT_OVERFLOW), 0xFFFFu) << 16);
@@ -830,16 +840,29 @@ namespace rtmi_dev {
 #ifndef RTMI_HOST_EMUL
 template <>
 void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hipStream_t st, const DScene<RTMI_REAL> &sc,
-                                     const DCamera<double> &cam, const DRender &rp, float *out, unsigned long long *stats, void *work,
+                                     const DCamera<double> &cam, const DRender &rp_, float *out, unsigned long long *stats, void *work,
                                      size_t work_bytes, hipEvent_t between, void *state_) {
+    const bool photon = sc.n_photons != 0; // (kernels of their own, tree kind, one lane per pixel: the host chooses tree = true, no spread)
+    // A photon scene in f32 mode: the tail of the work memory is the heap workspace (photon_estimate), if the memory is the
+    // pool's (the 96 MiB of the entry point that allocates nothing are too few: per-lane scratch there, as in f64 mode)
+    HeapEntry<RTMI_REAL> *heap_ws = nullptr;
+    DRender rp = rp_;
+    rp.heap_slots = 0;
+    if (sizeof(RTMI_REAL) == 4 && photon && work) {
+        const size_t heap_bytes = ((size_t)HEAP_WS_SLOTS * 64u * (size_t)HEAP_WS_ENTRIES * sizeof(HeapEntry<RTMI_REAL>) + 255u) & ~(size_t)255u;
+        if (work_bytes >= heap_bytes + ((size_t)512 << 20)) {
+            work_bytes -= heap_bytes;
+            heap_ws = (HeapEntry<RTMI_REAL> *)((char *)work + work_bytes);
+            rp.heap_slots = HEAP_WS_SLOTS;
+        }
+    }
     DWork<RTMI_REAL> wk = make_work<RTMI_REAL>(work, work_bytes);
     DPixelState<RTMI_REAL> *state = (DPixelState<RTMI_REAL> *)state_;
     const bool spread = rp.group > 1;
-    const bool photon = sc.n_photons != 0; // (kernels of their own, tree kind, one lane per pixel: the host chooses tree = true, no spread)
     const bool draw = RTMI_DRAW_VISITS && !spread && wk.hdr != nullptr && grid_resample > 0; // (an open-ended call: its visits are long and uneven)
     bool flatx = false; // a flat world with a transformed-sphere table: the KIND_FLATX kernels (f32 only)
     if constexpr (sizeof(RTMI_REAL) == 4) flatx = !tree && !photon && (sc.xpair_counts & 255u) != 0u;
-#define RTMI_LAUNCH_RENDER(...) hipLaunchKernelGGL((render_kernel<RTMI_REAL, __VA_ARGS__>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state)
+#define RTMI_LAUNCH_RENDER(...) hipLaunchKernelGGL((render_kernel<RTMI_REAL, __VA_ARGS__>), dim3(grid), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.cap, state, heap_ws)
     if (photon && draw) RTMI_LAUNCH_RENDER(true, false, true, true);
     else if (photon) RTMI_LAUNCH_RENDER(true, false, true, false);
     else if (tree && spread) RTMI_LAUNCH_RENDER(true, true, false, false);
@@ -862,16 +885,16 @@ void launch_render_kernel<RTMI_REAL>(bool tree, int grid, int grid_resample, hip
         const int pass = l <= RTMI_SPEC_PASSES ? l : -1;
         if (pass < 0 && RTMI_SPEC_PASSES == 0) break;
         if (pass > 0) {
-            if (photon) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
-            else if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
-            else if (flatx) { if constexpr (sizeof(RTMI_REAL) == 4) hipLaunchKernelGGL((units_kernel<RTMI_REAL, KIND_FLATX>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass); }
-            else hipLaunchKernelGGL((units_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass);
+            if (photon) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, heap_ws);
+            else if (tree) hipLaunchKernelGGL((units_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, heap_ws);
+            else if (flatx) { if constexpr (sizeof(RTMI_REAL) == 4) hipLaunchKernelGGL((units_kernel<RTMI_REAL, KIND_FLATX>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, heap_ws); }
+            else hipLaunchKernelGGL((units_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, wk.hdr, wk.heavy, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, heap_ws);
             hipLaunchKernelGGL(sum_up_kernel<RTMI_REAL>, dim3(grid_resample), dim3(64), 0, st, cam, out, stats, wk.hdr, wk.heavy, wk.final_idx, wk.unit_pixel, wk.chunks, wk.cap, wk.unit_cap, pass, state);
         } else {
-            if (photon) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
-            else if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
-            else if (flatx) { if constexpr (sizeof(RTMI_REAL) == 4) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, KIND_FLATX>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state); }
-            else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state);
+            if (photon) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state, heap_ws);
+            else if (tree) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, true>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state, heap_ws);
+            else if (flatx) { if constexpr (sizeof(RTMI_REAL) == 4) hipLaunchKernelGGL((resample_kernel<RTMI_REAL, KIND_FLATX>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state, heap_ws); }
+            else hipLaunchKernelGGL((resample_kernel<RTMI_REAL, false>), dim3(grid_resample), dim3(64), 0, st, sc, cam, rp, out, stats, wk.hdr, wk.light, wk.heavy, wk.final_idx, wk.unit_pixel, wk.cap, wk.unit_cap, pass, state, heap_ws);
         }
     }
 }
