@@ -1990,33 +1990,27 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
     R top = (R)0; // the root's distance while cnt > 0, in a register: it is looked at for every photon visited
     const R pc[3] = {p.x, p.y, p.z};
     uint32_t visited = 0;
-    // No stack: the tree is in heap order (parent of i: (i - 1) / 2), so the way back is arithmetic, and the stage each
-    // ancestor is in (0: its near side is next; 1: back from it; 2: back from the far side) takes two bits per level of a
-    // 64-bit word - the tree of 2^30 - 1 photons has 30 levels.
-    uint32_t node = 0, depth = 0;
-    unsigned long long stages = 0;
+    // No stack: the tree is in heap order (parent of i: (i - 1) / 2), so the way back is arithmetic, and what is left to do
+    // at each ancestor takes one bit per level (set: the walk is in its far side, nothing left) - the tree of 2^30 - 1
+    // photons has 30 levels.  The reference looks at a node's own photon AFTER both sides (locate_photons, photon_map.rs:
+    // 323-363); here it is looked at BETWEEN them, in the trip that comes back from the near side and decides about the
+    // far side, so that a node inside the tree costs two loads of its record and two trips of this loop instead of three.
+    // The photons found are the same: whatever the order, a photon enters the heap iff it is nearer than the k-th nearest
+    // so far, and a side is skipped only if its plane is at least that far away - the k nearest within the radius either
+    // way; the number of photons LOOKED AT on the way (RTMI_STAT_FLOPS' share) is not the reference's.
+    uint32_t node = 0, depth = 0, in_far = 0;
+    bool arriving = true; // from above (else: back from the near side of `node`)
     bool walking = n > 0 && k > 0;
     while (walking) { // (node < n here)
         const DPhoton &ph = sc.photons[node];
         const uint32_t left = 2u * node + 1u;
-        const uint32_t stage = (uint32_t)(stages >> (2u * depth)) & 3u;
-        bool self = stage == 2u || left >= n; // (is_leaf, photon_map.rs:376-378)
-        if (!self) {
-            const uint32_t axis = min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u);
-            const R d = pc[axis] - (R)ph.pos[axis];
-            uint32_t child = NONE;
-            unsigned long long next_stage = 0;
-            if (stage == 0u) { child = d < (R)0 ? left : left + 1u; next_stage = 1ull; }
-            else if ((d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < top)) { child = d < (R)0 ? left + 1u : left; next_stage = 2ull; }
-            else self = true;
-            if (!self) {
-                stages = (stages & ~(3ull << (2u * depth))) | (next_stage << (2u * depth));
-                if (child < n && depth < 31u) { // down (a child beyond the photons returns at once, photon_map.rs:330-332: this node again, next stage)
-                    node = child; ++depth;
-                    stages &= ~(3ull << (2u * depth));
-                }
-                continue;
-            }
+        const bool inner = left < n; // (!is_leaf, photon_map.rs:376-378)
+        R d = (R)0;
+        if (inner) d = pc[min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u)] - (R)ph.pos[min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u)];
+        if (arriving && inner) { // down the near side (a child beyond the photons returns at once, photon_map.rs:330-332)
+            const uint32_t child = d < (R)0 ? left : left + 1u;
+            in_far &= ~(1u << depth);
+            if (child < n && depth < 31u) { node = child; ++depth; continue; }
         }
         {
             const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
@@ -2064,8 +2058,19 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
                 top = new_top;
             }
         }
-        if (depth == 0u) walking = false; // back to the parent
-        else { node = (node - 1u) >> 1; --depth; }
+        if (inner && (d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < top)) { // the far side
+            const uint32_t child = d < (R)0 ? left + 1u : left;
+            if (child < n && depth < 31u) { in_far |= 1u << depth; node = child; ++depth; arriving = true; continue; }
+        }
+        // back up to the nearest ancestor whose near side this was (those in their far side are done)
+        const uint32_t open = ~in_far & ((1u << depth) - 1u);
+        if (open == 0u) walking = false;
+        else {
+            const uint32_t level = 31u - (uint32_t)__builtin_clz(open);
+            node = ((node + 1u) >> (depth - level)) - 1u;
+            depth = level;
+            arriving = false;
+        }
     }
     const R square_radius = cnt ? top : (R)1; // (unwrap_or(1.0), photon_map.rs:318)
     V3<R> total = mk<R>(0, 0, 0);
