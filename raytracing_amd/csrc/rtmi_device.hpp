@@ -2000,21 +2000,29 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
     // way; the number of photons LOOKED AT on the way (RTMI_STAT_FLOPS' share) is not the reference's.
     uint32_t node = 0, depth = 0, in_far = 0;
     bool arriving = true; // from above (else: back from the near side of `node`)
+    R kept_d = (R)0, kept_d2 = (R)0;
     bool walking = n > 0 && k > 0;
     while (walking) { // (node < n here)
         const DPhoton &ph = sc.photons[node];
         const uint32_t left = 2u * node + 1u;
         const bool inner = left < n; // (!is_leaf, photon_map.rs:376-378)
-        R d = (R)0;
-        if (inner) d = pc[min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u)] - (R)ph.pos[min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u)];
+        // (a node whose children are leaves - three quarters of the nodes a search looks at are in the tree's last two
+        // levels - is back from its near side one trip after it was left: what its record said is still in registers)
+        const bool kept = !arriving && 2u * left + 1u >= n;
+        R d = kept_d, d2 = kept_d2;
+        if (!kept) {
+            const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
+            d2 = dx * dx + dy * dy + dz * dz;
+            const uint32_t axis = min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u);
+            d = axis == 0u ? dx : axis == 1u ? dy : dz;
+        }
         if (arriving && inner) { // down the near side (a child beyond the photons returns at once, photon_map.rs:330-332)
             const uint32_t child = d < (R)0 ? left : left + 1u;
             in_far &= ~(1u << depth);
+            kept_d = d; kept_d2 = d2;
             if (child < n && depth < 31u) { node = child; ++depth; continue; }
         }
         {
-            const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
-            const R d2 = dx * dx + dy * dy + dz * dz;
             ++visited;
             // BinaryHeap (photon_map.rs:354-362) as one array of (distance, node) pairs, a max-heap with HEAP_ARITY
             // children per entry (half the levels of a binary one: every level is a round trip to per-lane memory).
