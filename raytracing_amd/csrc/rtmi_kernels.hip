@@ -14,6 +14,9 @@ using namespace rtmi_dev;
 #ifndef RTMI_WAVES_PHOTON
 #define RTMI_WAVES_PHOTON 3 // ... the kernels that gather from a photon map
 #endif
+#ifndef RTMI_PHOTON_STRIP
+#define RTMI_PHOTON_STRIP 32 // photon scenes: the first pass visits the frame's tiles in vertical strips this many tiles wide
+#endif
 #ifndef RTMI_WAVES_TREE
 #define RTMI_WAVES_TREE 3 // ... and the tree-scene kernels
 #endif
@@ -289,6 +292,20 @@ __global__ void __launch_bounds__(64, PHOTON ? RTMI_WAVES_PHOTON : TREE == KIND_
         const unsigned long long q = (unsigned long long)visit * rp.ppw + slot_k;
         const int tile = (int)(q >> 6), in_tile = (int)(q & 63u);
         int ltr = tile / rp.tiles_x, tx = tile - ltr * rp.tiles_x;
+        if constexpr (PHOTON) {
+            // The gather is bound by the memory system (each estimate reads some thousand photon records, every lane its
+            // own), and the waves in flight are ~2,000 consecutive tiles: in row-major order a band four tiles high across
+            // the whole frame.  Tiles in strips RTMI_PHOTON_STRIP wide instead - a compact block of the picture, whose
+            // searches meet in a smaller part of the map that the L2s and the MALL hold on to.
+            const int W = RTMI_PHOTON_STRIP, rows = rp.n_tiles / rp.tiles_x, whole = rp.tiles_x / W, per_strip = W * rows;
+            if (tile < whole * per_strip) {
+                const int strip = tile / per_strip, t = tile - strip * per_strip;
+                ltr = t / W; tx = strip * W + (t - ltr * W);
+            } else if (tile < rp.n_tiles) {
+                const int t = tile - whole * per_strip, rem = rp.tiles_x - whole * W;
+                ltr = t / rem; tx = whole * W + (t - ltr * rem);
+            }
+        }
         int lt = ltr / sub, within = ltr - lt * sub;
         int gt = lt * rp.nranks + rp.rank;
         const int x = tx * 8 + (in_tile & 7), y = (gt * sub + within) * 8 + (in_tile >> 3);
