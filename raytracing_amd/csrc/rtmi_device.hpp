@@ -1968,6 +1968,7 @@ constexpr int HEAP_LDS = RTMI_HEAP_LDS; // entries of the heap held in LDS (21: 
 // 1080p frame moved).  The render kernels therefore get a workspace in the call's work memory, LANE-major: a lane's
 // entries are one contiguous run of 8-byte pairs, the four children of a heap entry share a 64-byte line (heap_ws: the
 // lane's own run, or null - the probe kernels, the f64 mode, work memory too small - for the scratch array).
+constexpr bool HEAP_LEVELS_WHOLE = HEAP_ARITY == 4 && (HEAP_LDS == 1 || HEAP_LDS == 5 || HEAP_LDS == 21 || HEAP_LDS == 85); // the LDS part ends with a level
 constexpr int HEAP_WS_ENTRIES = RTMI_MAX_NEAREST - HEAP_LDS; // pairs per lane
 constexpr uint32_t HEAP_WS_SLOTS = 4096;                     // waves per launch that can have a run each (the host caps the grids of photon kernels at this)
 template <typename R>
@@ -2049,13 +2050,35 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
                     const int c0 = HEAP_ARITY * i + 1;
                     if (c0 >= cnt) break;
                     const int last = cnt - 1;
-                    HeapEntry<R> c = heap_ld(c0);
+                    HeapEntry<R> c;
                     int m = c0;
+                    // (independent loads: one round trip per level; a clamped index repeats the last child.  With whole
+                    // levels in LDS the children of one entry are all on the same side of HEAP_LDS: one choice of home
+                    // per level instead of one per load)
+                    if (HEAP_LEVELS_WHOLE && c0 < HEAP_LDS) {
+                        c = heap_top[c0][heap_lane];
 #pragma unroll
-                    for (int j = 1; j < HEAP_ARITY; ++j) { // (independent loads: one round trip per level; a clamped index repeats the last child)
-                        const int at = min(c0 + j, last);
-                        const HeapEntry<R> e = heap_ld(at);
-                        if (c.d < e.d) { c = e; m = at; }
+                        for (int j = 1; j < HEAP_ARITY; ++j) {
+                            const int at = min(c0 + j, last);
+                            const HeapEntry<R> e = heap_top[at][heap_lane];
+                            if (c.d < e.d) { c = e; m = at; }
+                        }
+                    } else if (HEAP_LEVELS_WHOLE && heap_ws) {
+                        c = heap_ws[c0 - HEAP_LDS];
+#pragma unroll
+                        for (int j = 1; j < HEAP_ARITY; ++j) {
+                            const int at = min(c0 + j, last);
+                            const HeapEntry<R> e = heap_ws[at - HEAP_LDS];
+                            if (c.d < e.d) { c = e; m = at; }
+                        }
+                    } else {
+                        c = heap_ld(c0);
+#pragma unroll
+                        for (int j = 1; j < HEAP_ARITY; ++j) {
+                            const int at = min(c0 + j, last);
+                            const HeapEntry<R> e = heap_ld(at);
+                            if (c.d < e.d) { c = e; m = at; }
+                        }
                     }
                     if (!(d2 < c.d)) break;
                     heap_st(i, c);
