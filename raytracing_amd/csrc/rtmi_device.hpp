@@ -1969,6 +1969,9 @@ constexpr int HEAP_LDS = RTMI_HEAP_LDS; // entries of the heap held in LDS (21: 
 // entries are one contiguous run of 8-byte pairs, the four children of a heap entry share a 64-byte line (heap_ws: the
 // lane's own run, or null - the probe kernels, the f64 mode, work memory too small - for the scratch array).
 constexpr bool HEAP_LEVELS_WHOLE = HEAP_ARITY == 4 && (HEAP_LDS == 1 || HEAP_LDS == 5 || HEAP_LDS == 21 || HEAP_LDS == 85); // the LDS part ends with a level
+__device__ __host__ constexpr int heap_level_start(int level) { int at = 0, w = 1; for (int l = 0; l < level; ++l) { at += w; w *= HEAP_ARITY; } return at; } // 0, 1, 5, 21, 85, ...
+__device__ __host__ constexpr int heap_parent_levels() { int l = 0; while (heap_level_start(l + 1) < RTMI_MAX_NEAREST) ++l; return l; }
+constexpr int HEAP_PARENT_LEVELS = heap_parent_levels(); // levels whose entries can have children (4 at 128 candidates)
 constexpr int HEAP_WS_ENTRIES = RTMI_MAX_NEAREST - HEAP_LDS; // pairs per lane
 constexpr uint32_t HEAP_WS_SLOTS = 4096;                     // waves per launch that can have a run each (the host caps the grids of photon kernels at this)
 template <typename R>
@@ -2046,6 +2049,45 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
             } else if (d2 < top) {
                 int i = 0;
                 R new_top = d2;
+                if (HEAP_LEVELS_WHOLE && heap_ws) {
+                    // The hole sinks one level per step, in every lane: step by step unrolled, where an entry and its
+                    // children live is known when the code is written, not looked up per access.
+                    bool sinking = true;
+#pragma unroll
+                    for (int lvl = 0; lvl < HEAP_PARENT_LEVELS; ++lvl) {
+                        const int c0 = HEAP_ARITY * i + 1;
+                        sinking = sinking && c0 < cnt;
+                        if (sinking) {
+                            const int last = cnt - 1;
+                            HeapEntry<R> c;
+                            int m = c0;
+                            if (heap_level_start(lvl + 1) < HEAP_LDS) {
+                                c = heap_top[c0][heap_lane];
+#pragma unroll
+                                for (int j = 1; j < HEAP_ARITY; ++j) {
+                                    const int at = min(c0 + j, last);
+                                    const HeapEntry<R> e = heap_top[at][heap_lane];
+                                    if (c.d < e.d) { c = e; m = at; }
+                                }
+                            } else {
+                                c = heap_ws[c0 - HEAP_LDS];
+#pragma unroll
+                                for (int j = 1; j < HEAP_ARITY; ++j) {
+                                    const int at = min(c0 + j, last);
+                                    const HeapEntry<R> e = heap_ws[at - HEAP_LDS];
+                                    if (c.d < e.d) { c = e; m = at; }
+                                }
+                            }
+                            if (!(d2 < c.d)) sinking = false;
+                            else {
+                                if (heap_level_start(lvl) < HEAP_LDS) heap_top[i][heap_lane] = c;
+                                else heap_ws[i - HEAP_LDS] = c;
+                                if (lvl == 0) new_top = c.d;
+                                i = m;
+                            }
+                        }
+                    }
+                } else
                 for (;;) {
                     const int c0 = HEAP_ARITY * i + 1;
                     if (c0 >= cnt) break;
