@@ -1997,33 +1997,30 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
     // No stack: the tree is in heap order (parent of i: (i - 1) / 2), so the way back is arithmetic, and what is left to do
     // at each ancestor takes one bit per level (set: the walk is in its far side, nothing left) - the tree of 2^30 - 1
     // photons has 30 levels.  The reference looks at a node's own photon AFTER both sides (locate_photons, photon_map.rs:
-    // 323-363); here it is looked at BETWEEN them, in the trip that comes back from the near side and decides about the
-    // far side, so that a node inside the tree costs two loads of its record and two trips of this loop instead of three.
+    // 323-363).  Here a node inside the tree is looked at BETWEEN them, in the trip that comes back from the near side and
+    // decides about the far side - two loads of its record and two trips of this loop instead of three; and a node whose
+    // children are leaves (`low`: three quarters of the nodes a search looks at are in the tree's last two levels) BEFORE
+    // them, in the trip that arrives at it, its distance to the plane kept in a register for the near leaf's trip to
+    // decide about the far leaf - three trips and three loads for the three.
     // The photons found are the same: whatever the order, a photon enters the heap iff it is nearer than the k-th nearest
     // so far, and a side is skipped only if its plane is at least that far away - the k nearest within the radius either
     // way; the number of photons LOOKED AT on the way (RTMI_STAT_FLOPS' share) is not the reference's.
     uint32_t node = 0, depth = 0, in_far = 0;
     bool arriving = true; // from above (else: back from the near side of `node`)
-    R kept_d = (R)0, kept_d2 = (R)0;
+    R kept_d = (R)0;      // of the last low node arrived at
     bool walking = n > 0 && k > 0;
     while (walking) { // (node < n here)
         const DPhoton &ph = sc.photons[node];
         const uint32_t left = 2u * node + 1u;
         const bool inner = left < n; // (!is_leaf, photon_map.rs:376-378)
-        // (a node whose children are leaves - three quarters of the nodes a search looks at are in the tree's last two
-        // levels - is back from its near side one trip after it was left: what its record said is still in registers)
-        const bool kept = !arriving && 2u * left + 1u >= n;
-        R d = kept_d, d2 = kept_d2;
-        if (!kept) {
-            const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
-            d2 = dx * dx + dy * dy + dz * dz;
-            const uint32_t axis = min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u);
-            d = axis == 0u ? dx : axis == 1u ? dy : dz;
-        }
-        if (arriving && inner) { // down the near side (a child beyond the photons returns at once, photon_map.rs:330-332)
+        const bool low = inner && 2u * left + 1u >= n;
+        const R dx = pc[0] - (R)ph.pos[0], dy = pc[1] - (R)ph.pos[1], dz = pc[2] - (R)ph.pos[2];
+        const R d2 = dx * dx + dy * dy + dz * dz;
+        const uint32_t axis = min((ph.rgbf >> 24) - (uint32_t)KD_SPLIT_X, 2u);
+        const R d = axis == 0u ? dx : axis == 1u ? dy : dz;
+        if (arriving && inner && !low) { // down the near side (a child beyond the photons returns at once, photon_map.rs:330-332)
             const uint32_t child = d < (R)0 ? left : left + 1u;
             in_far &= ~(1u << depth);
-            kept_d = d; kept_d2 = d2;
             if (child < n && depth < 31u) { node = child; ++depth; continue; }
         }
         {
@@ -2131,9 +2128,27 @@ __device__ __forceinline__ V3<R> photon_estimate(const DScene<R> &sc, V3<R> p, V
                 top = new_top;
             }
         }
+        if (low && arriving) { // its near leaf
+            const uint32_t child = d < (R)0 ? left : left + 1u;
+            in_far &= ~(1u << depth);
+            kept_d = d;
+            if (child < n && depth < 31u) { node = child; ++depth; continue; }
+        }
         if (inner && (d < (R)0 ? -d : d) < sc.photon_radius && (cnt < k || d * d < top)) { // the far side
             const uint32_t child = d < (R)0 ? left + 1u : left;
             if (child < n && depth < 31u) { in_far |= 1u << depth; node = child; ++depth; arriving = true; continue; }
+        }
+        if (!inner && depth > 0u && (in_far >> (depth - 1u) & 1u) == 0u) {
+            // the near leaf of a low node (4 * parent + 3, the first grandchild, is no photon): the far leaf is its sibling,
+            // and the parent's kept distance decides about it; either way the parent is done
+            const uint32_t parent = (node - 1u) >> 1;
+            if (4u * parent + 3u >= n) {
+                in_far |= 1u << (depth - 1u);
+                const uint32_t sibling = (node & 1u) ? node + 1u : node - 1u;
+                if ((kept_d < (R)0 ? -kept_d : kept_d) < sc.photon_radius && (cnt < k || kept_d * kept_d < top) && sibling < n) {
+                    node = sibling; arriving = true; continue;
+                }
+            }
         }
         // back up to the nearest ancestor whose near side this was (those in their far side are done)
         const uint32_t open = ~in_far & ((1u << depth) - 1u);
