@@ -50,7 +50,7 @@ def test_random_rays_against_the_oracle(direct, n_nearest, radius):
         assert ref.max() > 1e-3  # (the map is all the light there is: the comparison is of the estimate)
 
 
-@pytest.mark.parametrize("n_photons", [1, 2, 3, 5, 8, 64])
+@pytest.mark.parametrize("n_photons", [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 64])
 def test_small_and_degenerate_maps(n_photons):
     """Maps of a handful of photons (every shape of the left-balanced tree's last level), more neighbours asked for than there
     are photons, and coincident photons (both sides order equal coordinates by index): f64 colours equal the oracle's."""
