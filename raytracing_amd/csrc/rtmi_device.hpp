@@ -179,10 +179,12 @@ struct alignas(16) DChain { unsigned long long zero, one; };
 // A photon of the map (photon_map.rs:15-20) as the device reads it: 32 bytes, the bytes of the compressed power and the
 // flag PhotonMap::balance gave the photon (photon_map.rs:215-221) in one word.
 enum { KD_LEAF = 1, KD_SPLIT_X = 2, KD_SPLIT_Y = 3, KD_SPLIT_Z = 4 };
-struct DPhoton {
-    float pos[3], dir[3], scale;
+struct alignas(16) DPhoton { // (what the search reads of a node - position and flag - is the record's first 16 bytes: one load)
+    float pos[3];
     uint32_t rgbf; // r | g << 8 | b << 16 | kd flag << 24
+    float dir[3], scale;
 };
+static_assert(sizeof(DPhoton) == 32, "DPhoton is 32 bytes");
 constexpr int PHOTON_STACK = 64; // entries of the search's stack: two per level of a tree of at most 2^30 photons
 
 template <typename R> struct DScene {
