@@ -326,7 +326,7 @@ struct rtmi_scene {
     DNode *nodes = nullptr;
     DCsg *csgs = nullptr;
     DChain *csg_chain = nullptr;
-    DPhoton *photons = nullptr; // World::photon_map in kd-tree order
+    DPhoton *photons = nullptr; // World::photon_map in kd-tree order, behind one unused record (rtmi_scene_create)
     uint32_t n_photons = 0;
     uint32_t *leaf_orig = nullptr;
     DWTri *wtris = nullptr;
@@ -1406,7 +1406,7 @@ static int upload_typed(const rtmi_scene_desc *d, const Layout &L, DeviceArrays<
 template <typename R> static void header(const rtmi_scene *s, const rtmi_scene_desc *d, const Layout &L, const DeviceArrays<R> &A, DScene<R> &h) {
     h.leaves = A.leaves; h.tris = A.tris; h.materials = A.materials; h.patterns = A.patterns; h.lights = A.lights;
     h.nodes = s->nodes; h.csgs = s->csgs; h.csg_leaf = A.csg_leaf; h.csg_chain = s->csg_chain;
-    h.photons = s->n_photons ? s->photons : nullptr; h.n_photons = s->n_photons; h.n_nearest = s->n_photons ? (uint32_t)d->n_nearest : 0u;
+    h.photons = s->n_photons ? s->photons + 1 : nullptr; h.n_photons = s->n_photons; h.n_nearest = s->n_photons ? (uint32_t)d->n_nearest : 0u;
     h.no_direct = d->no_direct_illumination ? 1u : 0u; h.pad3 = 0;
     h.photon_radius = d->max_search_radius > 0.0 ? (R)d->max_search_radius : (R)INFINITY; h.leaf_orig = s->leaf_orig;
     h.wtris = sizeof(R) == 4 ? s->wtris : nullptr;
@@ -1547,7 +1547,14 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *desc, rtmi_scene **out) 
     if (rc == RTMI_OK) rc = upload(&s->btris, btris);
     if (rc == RTMI_OK) rc = upload(&s->csgs, L.csgs);
     if (rc == RTMI_OK) rc = upload(&s->csg_chain, L.chains());
-    if (rc == RTMI_OK && desc->n_photons > 0) { s->n_photons = (uint32_t)desc->n_photons; rc = upload(&s->photons, balance_photons(desc->photons, desc->n_photons)); }
+    if (rc == RTMI_OK && desc->n_photons > 0) {
+        // (one unused record in front: node 0 then lies 32 bytes into the allocation and the two children of a node - the
+        // near leaf and the far leaf that most searches look at one after the other - share one 64-byte sector)
+        std::vector<DPhoton> tree = balance_photons(desc->photons, desc->n_photons);
+        tree.insert(tree.begin(), tree.front());
+        s->n_photons = (uint32_t)desc->n_photons;
+        rc = upload(&s->photons, tree);
+    }
     if (rc == RTMI_OK) rc = upload(&s->leaf_orig, L.leaf_orig);
     QuickTables qt;
     if (rc == RTMI_OK) rc = upload_typed<float>(desc, L, s->f32, &qt);
